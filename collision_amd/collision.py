@@ -1,0 +1,119 @@
+"""Broad-phase sphere collision: scene bounds -> Morton codes -> radix sort -> Karras LBVH ->
+AABB refit -> pair-overlap traversal.
+
+Mirrors ``collision/collision.py`` (Node :9, NO_NODE :11, CollisionProgram :13-29,
+Collider :32-198): same constructor, ``resize``, ``n_nodes``, ``padded_size`` and
+``get_collisions(cq, coords_buf, radii_buf, n_collisions_buf, collisions_buf, n_collisions,
+wait_for)``, same ``ValueError`` contract.  The ~76 PyOpenCL enqueues of the reference become one
+C-ABI call, ``col_collide``, which enqueues the whole chain on the caller's HIP stream.
+"""
+import numpy as np
+
+from . import hip
+from ._lib import call
+from .bounds import Bounds
+from .misc import ProgramHandle, np_float_dtypes, roundUp
+from .radix import RadixSorter
+
+# 16-byte node record (collision.py:9, collision.cl:42-53)
+Node = np.dtype([("parent", "uint32"), ("right_edge", "uint32"), ("data", "uint32", 2)])
+NO_NODE = np.iinfo(np.uint32).max
+
+
+class CollisionProgram(ProgramHandle):
+    """Typed handle (collision.py:13-29): the coordinate dtype the kernels are specialised for."""
+
+    def __init__(self, ctx, coord_dtype=np.dtype("float32")):
+        coord_dtype = np.dtype(coord_dtype)
+        if coord_dtype.name not in np_float_dtypes:
+            raise ValueError("Invalid dtype: {}".format(coord_dtype))
+        if coord_dtype.itemsize not in (4, 8):
+            raise ValueError("Unsupported coordinate dtype on this device path: {}".format(coord_dtype))
+        self.coord_dtype = coord_dtype
+        super().__init__(ctx)
+
+
+class Collider:
+    code_dtype = np.dtype("uint32")
+    flag_dtype = np.dtype("uint32")
+    counter_dtype = np.dtype("uint32")
+    id_dtype = np.dtype("uint32")
+
+    def __init__(self, ctx, size, ngroups, group_size, coord_dtype=np.dtype("float32"),
+                 program=None, sorter_programs=(None, None), reducer_program=None):
+        coord_dtype = np.dtype(coord_dtype)
+        self.size = size
+        self.group_size = group_size
+        self.sorter = RadixSorter(ctx, self.padded_size, group_size, key_dtype=self.code_dtype,
+                                  value_dtype=self.id_dtype, program=sorter_programs[0],
+                                  scan_program=sorter_programs[1])
+        self.reducer = Bounds(ctx, ngroups, group_size, coord_dtype=np.dtype((coord_dtype, 3)),
+                              program=reducer_program)
+        if program is None:
+            program = CollisionProgram(ctx, coord_dtype)
+        else:
+            if program.context != ctx:
+                raise ValueError("Collider and program context must match")
+            if program.coord_dtype != coord_dtype:
+                raise ValueError("Collider and program coord_dtype must match")
+        self.program = program
+        self._alloc = {}              # device scratch, (re)allocated at first use after a size change
+
+    # -- sizes -----------------------------------------------------------------
+    @property
+    def n_nodes(self):
+        return 2 * self.size - 1
+
+    @property
+    def padded_size(self):
+        # the sorter wants a multiple of 2 * group_size (collision.py:125-128)
+        return roundUp(self.size, 2 * self.group_size)
+
+    def _allocate(self):
+        """(Re)allocate only the scratch whose size changed (collision.py:61-82,104-119)."""
+        ctx = self.program.context
+        coord_bytes = self.program.coord_dtype.itemsize
+        want = {
+            "ids0": self.padded_size * 4, "ids1": self.padded_size * 4,
+            "codes0": self.padded_size * 4, "codes1": self.padded_size * 4,
+            "nodes": self.n_nodes * Node.itemsize,
+            "bounds": self.n_nodes * 2 * 4 * coord_bytes,     # also carries the traversal links
+            "flags": self.n_nodes * 4,
+            "scratch": call.col_collide_scratch_bytes(self.size, self.padded_size, coord_bytes),
+        }
+        for name, nbytes in want.items():
+            if name not in self._alloc or self._alloc[name].size != nbytes:
+                self._alloc[name] = hip.Buffer(ctx, nbytes)
+        a = self._alloc
+        self._ids_bufs = [a["ids0"], a["ids1"]]
+        self._codes_bufs = [a["codes0"], a["codes1"]]
+        self._nodes_buf, self._bounds_buf, self._flags_buf = a["nodes"], a["bounds"], a["flags"]
+
+    def resize(self, size=None, ngroups=None, group_size=None, radix_bits=None):
+        if size is not None:
+            self.size = size
+        if group_size is not None:
+            self.group_size = group_size
+        # The reference passes roundUp(size, group_size) here (collision.py:95), which fails its
+        # own sorter's size rule for odd multiples of group_size; padded_size is what it means.
+        self.sorter.resize(self.padded_size, group_size, radix_bits)
+        self.reducer.resize(ngroups, group_size)
+
+    # -- the path --------------------------------------------------------------
+    def get_collisions(self, cq, coords_buf, radii_buf, n_collisions_buf, collisions_buf, n_collisions,
+                       wait_for=None):
+        """Enqueue the whole path.  n_collisions_buf (1 uint32) receives the TOTAL number of
+        overlapping pairs; the first ``n_collisions`` of them are written to collisions_buf as
+        (id, id) rows, in no particular order.  collisions_buf may be None when n_collisions == 0
+        (count-only mode, collision.py:134-135)."""
+        if collisions_buf is None and n_collisions > 0:
+            raise ValueError("Invalid collisions_buf for n_collisions > 0")
+        self._allocate()
+        cq.wait_for(wait_for)
+        call.col_collide(
+            cq.stream, coords_buf.ptr, radii_buf.ptr, self.size, self.padded_size,
+            self.program.coord_dtype.itemsize,
+            self._codes_bufs[0].ptr, self._codes_bufs[1].ptr, self._ids_bufs[0].ptr, self._ids_bufs[1].ptr,
+            self._nodes_buf.ptr, self._bounds_buf.ptr, self._flags_buf.ptr, self._alloc["scratch"].ptr,
+            n_collisions_buf.ptr, None if collisions_buf is None else collisions_buf.ptr, n_collisions)
+        return hip.Event(cq)

@@ -1,0 +1,263 @@
+// Karras LBVH build, AABB refit and pair-overlap traversal.
+// Replaces fillInternal / generateBVH / leafBounds / internalBounds / traverse
+// (collision/collision.cl:55-226, enqueued at collision/collision.py:171-196).
+//
+// Outputs `nodes` (16 B records) and `bounds` (2 x vec4 per node) exactly as the reference
+// lays them out: internal nodes [0, n-1), leaves [n-1, 2n-1) in sorted order, root 0.
+//
+// MI355X shape of the traversal: the reference walks from the root with a 64-entry private
+// stack and touches 5 cache lines per step (node, two child nodes, two child bounds).  Here
+// the unused lane w of every node's Bound carries two links written at build time --
+//     min.w = "skip": the node that follows this subtree in depth-first order,
+//     max.w = left child (internal) or sphere id (leaf)
+// -- so a traversal step is ONE 32-byte record (two float4 loads) and needs no stack.  A
+// query for sorted leaf q only has to report leaves p > q (collision.cl:199-200), and those
+// are exactly the subtrees hanging to the right of q's root path, i.e. the chain
+// skip(leaf q), skip(skip(leaf q)), ...; it never visits the part of the tree left of q.
+// Karras numbering makes skip() local: the right child that starts at leaf k is internal
+// node k when node k's range runs forward, else leaf k (see right_child_at()).
+#include "col_common.h"
+
+namespace {
+
+constexpr u32 END = 0xFFFFFFFFu;
+
+template <typename T> struct BTypes;
+template <> struct BTypes<float> {
+    typedef float4 V4;
+    typedef uint32_t Bits;
+    struct alignas(4) V3 { float x, y, z; };
+};
+template <> struct BTypes<double> {
+    typedef double4 V4;
+    typedef uint64_t Bits;
+    struct alignas(8) V3 { double x, y, z; };
+};
+
+// bounds are addressed as rows of 4 scalars: row 2*node = min, row 2*node+1 = max
+template <typename T> __device__ __forceinline__ u32 link_load(const T *bounds, uint64_t row) {
+    typedef typename BTypes<T>::Bits Bits;
+    return (u32) reinterpret_cast<const Bits *>(bounds)[row * 4 + 3];
+}
+template <typename T> __device__ __forceinline__ void link_store(T *bounds, uint64_t row, u32 v) {
+    typedef typename BTypes<T>::Bits Bits;
+    reinterpret_cast<Bits *>(bounds)[row * 4 + 3] = (Bits)v;
+}
+
+// collision.cl:65-77 delta(i, j): common-prefix length of codes i and j, index bits as the
+// tie-break for equal codes, -1 outside [0, n).
+__device__ __forceinline__ int delta(const u32 *__restrict__ codes, u32 n, u32 i, u32 ci, int64_t j) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    const u32 cj = codes[j];
+    return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
+}
+
+// The right child whose range starts at leaf k (1 <= k <= n-1): internal node k if that
+// node's range runs forward from k, otherwise the single leaf k.
+__device__ __forceinline__ u32 right_child_at(const u32 *__restrict__ codes, u32 n, u32 k) {
+    if (k + 1 >= n) return (n - 1) + k;
+    const u32 ck = codes[k];
+    const bool fwd = delta(codes, n, k, ck, (int64_t)k + 1) > delta(codes, n, k, ck, (int64_t)k - 1);
+    return fwd ? k : (n - 1) + k;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_build(const u32 *__restrict__ codes, const u32 *__restrict__ ids,
+                                                col_node *__restrict__ nodes, T *__restrict__ bounds, u32 n) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 leaf_start = n - 1;
+
+    // collision.cl:55-63 (fillInternal fills the leaves)
+    const u32 id = ids[i];
+    nodes[leaf_start + i].right_edge = i;
+    nodes[leaf_start + i].data[0] = id;
+    if (bounds) {
+        const uint64_t row = 2ull * (leaf_start + i);
+        link_store(bounds, row, i + 1 < n ? right_child_at(codes, n, i + 1) : END);
+        link_store(bounds, row + 1, id);
+    }
+    if (i >= leaf_start) return;
+
+    // collision.cl:81-121 (Karras 2012)
+    const u32 ci = codes[i];
+    const int dir = delta(codes, n, i, ci, (int64_t)i + 1) > delta(codes, n, i, ci, (int64_t)i - 1) ? 1 : -1;
+    const int delta_min = delta(codes, n, i, ci, (int64_t)i - dir);
+    int64_t len_max = 2;
+    while (delta(codes, n, i, ci, (int64_t)i + dir * len_max) > delta_min) len_max *= 2;
+    int64_t len = 0;
+    for (int64_t t = len_max / 2; t > 0; t /= 2)
+        if (delta(codes, n, i, ci, (int64_t)i + dir * (len + t)) > delta_min) len += t;
+    const u32 j = (u32)((int64_t)i + dir * len);
+    const int delta_node = delta(codes, n, i, ci, (int64_t)j);
+    int64_t s = 0, t = len;
+    do {
+        t = (t + 1) / 2;
+        if (delta(codes, n, i, ci, (int64_t)i + dir * (s + t)) > delta_node) s += t;
+    } while (t > 1);
+    const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
+    const u32 lo = min(i, j), hi = max(i, j);
+    const u32 child_a = (lo == gamma) ? leaf_start + gamma : gamma;
+    const u32 child_b = (hi == gamma + 1) ? leaf_start + gamma + 1 : gamma + 1;
+
+    nodes[i].right_edge = hi;
+    nodes[i].data[0] = child_a;
+    nodes[i].data[1] = child_b;
+    nodes[child_a].parent = i;
+    nodes[child_b].parent = i;
+    if (bounds) {
+        link_store(bounds, 2ull * i, hi + 1 < n ? right_child_at(codes, n, hi + 1) : END);
+        link_store(bounds, 2ull * i + 1, child_a);
+    }
+}
+
+// leafBounds + internalBounds (collision.cl:128-162) in one launch.  The thread that arrives
+// second at a node already holds one child's box in registers and loads only the sibling's.
+// Inter-workgroup hand-off: bounds stores -> agent-scope release fence -> flag atomic;
+// second arriver: flag atomic -> agent-scope acquire fence -> plain loads (per-XCD L2s are
+// not coherent; cdna_hip_programming.md guideline 16).
+template <typename T>
+__global__ __launch_bounds__(256) void k_refit(T *__restrict__ bounds, u32 *__restrict__ flags,
+                                                const T *__restrict__ coords, const T *__restrict__ radii,
+                                                const col_node *__restrict__ nodes, u32 n) {
+    typedef typename BTypes<T>::V4 V4;
+    typedef typename BTypes<T>::V3 V3;
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 leaf_start = n - 1;
+    u32 cur = leaf_start + i;
+    const u32 id = nodes[cur].data[0];
+    const V4 c = reinterpret_cast<const V4 *>(coords)[id];
+    const T r = radii[id];
+    V3 mn = {c.x - r, c.y - r, c.z - r};
+    V3 mx = {c.x + r, c.y + r, c.z + r};
+    *reinterpret_cast<V3 *>(bounds + 8ull * cur) = mn;
+    *reinterpret_cast<V3 *>(bounds + 8ull * cur + 4) = mx;
+    if (n < 2) return;
+    do {
+        const u32 parent = nodes[cur].parent;
+        __threadfence();
+        if (atomicAdd(&flags[parent], 1u) < 1u) break;   // first arrival: the sibling finishes the node
+        __threadfence();
+        const u32 ca = nodes[parent].data[0], cb = nodes[parent].data[1];
+        const u32 sib = ca == cur ? cb : ca;
+        const V4 smn = reinterpret_cast<const V4 *>(bounds)[2ull * sib];
+        const V4 smx = reinterpret_cast<const V4 *>(bounds)[2ull * sib + 1];
+        mn.x = smn.x < mn.x ? smn.x : mn.x; mn.y = smn.y < mn.y ? smn.y : mn.y; mn.z = smn.z < mn.z ? smn.z : mn.z;
+        mx.x = smx.x > mx.x ? smx.x : mx.x; mx.y = smx.y > mx.y ? smx.y : mx.y; mx.z = smx.z > mx.z ? smx.z : mx.z;
+        *reinterpret_cast<V3 *>(bounds + 8ull * parent) = mn;
+        *reinterpret_cast<V3 *>(bounds + 8ull * parent + 4) = mx;
+        cur = parent;
+    } while (cur != 0);
+}
+
+// traverse (collision.cl:174-226): pairs (id[q], id[p]) for every sorted leaf p > q whose box
+// strictly overlaps q's (collision.cl:164-166); the counter counts every hit, pairs beyond
+// `capacity` are dropped (collision.cl:203-207).  One hit append per wave-instruction:
+// ballot + mbcnt + a single atomic by the lowest hitting lane.
+template <typename T>
+__global__ __launch_bounds__(256) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
+                                                   const T *__restrict__ bounds, u32 n) {
+    typedef typename BTypes<T>::V4 V4;
+    typedef typename BTypes<T>::Bits Bits;
+    const u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 leaf_start = n - 1;
+    const V4 *rows = reinterpret_cast<const V4 *>(bounds);
+    const V4 qmn = rows[2ull * (leaf_start + q)], qmx = rows[2ull * (leaf_start + q) + 1];
+    const u32 qid = (u32) * reinterpret_cast<const Bits *>(&qmx.w);
+    u32 idx = (u32) * reinterpret_cast<const Bits *>(&qmn.w);
+    const u32 lane = lane_id();
+    while (idx != END) {
+        const V4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
+        const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+        const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
+        const bool overlap = qmx.x > a.x && qmn.x < b.x && qmx.y > a.y && qmn.y < b.y && qmx.z > a.z && qmn.z < b.z;
+        const bool leaf = idx >= leaf_start;
+        const bool hit = overlap && leaf;
+        const u64 hits = __ballot(hit);
+        if (hit) {
+            const int leader = (int)__builtin_ctzll(hits);
+            u32 base = 0;
+            if ((int)lane == leader) base = atomicAdd(counter, (u32)__popcll(hits));
+            base = __shfl(base, leader, COL_WAVE);
+            const u32 k = base + mbcnt(hits);
+            if (k < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * k) = make_uint2(qid, down);
+        }
+        idx = (overlap && !leaf) ? down : skip;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int col_bvh_build(void *stream, const uint32_t *codes, const uint32_t *ids, col_node *nodes, void *bounds,
+                  uint32_t n, int coord_bytes) {
+    if (n == 0) return COL_OK;
+    if (n >= 0x80000000u) return COL_EINVAL;
+    dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
+    if (coord_bytes == 4) k_build<float><<<grid, block, 0, col_stream(stream)>>>(codes, ids, nodes, (float *)bounds, n);
+    else if (coord_bytes == 8) k_build<double><<<grid, block, 0, col_stream(stream)>>>(codes, ids, nodes, (double *)bounds, n);
+    else return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coords, const void *radii,
+                  const col_node *nodes, uint32_t n, int coord_bytes) {
+    if (n == 0) return COL_OK;
+    dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
+    if (coord_bytes == 4)
+        k_refit<float><<<grid, block, 0, col_stream(stream)>>>((float *)bounds, flags, (const float *)coords, (const float *)radii, nodes, n);
+    else if (coord_bytes == 8)
+        k_refit<double><<<grid, block, 0, col_stream(stream)>>>((double *)bounds, flags, (const double *)coords, (const double *)radii, nodes, n);
+    else return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
+                 const void *bounds, uint32_t n, int coord_bytes) {
+    (void)nodes;   // the traversal runs on the 32-byte records in `bounds` alone
+    if (n < 2) return COL_OK;
+    if (capacity > 0 && !pairs) return COL_EINVAL;
+    dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
+    if (coord_bytes == 4) k_traverse<float><<<grid, block, 0, col_stream(stream)>>>(pairs, counter, capacity, (const float *)bounds, n);
+    else if (coord_bytes == 8) k_traverse<double><<<grid, block, 0, col_stream(stream)>>>(pairs, counter, capacity, (const double *)bounds, n);
+    else return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
+    (void)n;
+    return 256 /* scene range */ + col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4) +
+           col_radix_scratch_bytes(padded, 4, 4) + 256;
+}
+
+int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
+                uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
+                uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity) {
+    if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
+    if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
+    if (!scratch) return COL_ENOSCRATCH;
+    hipStream_t s = col_stream(stream);
+    COL_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), s));                 // collision.py:151-154
+    if (n == 0) return COL_OK;
+    COL_HIP(hipMemsetAsync(flags, 0, (size_t)(2ull * n - 1) * sizeof(uint32_t), s));   // collision.py:147-150
+    char *p = (char *)scratch;
+    void *range = p;           p += 256;
+    void *red_scratch = p;     p += col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4);
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    void *sort_scratch = p;
+    int rc;
+    if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
+    if ((rc = col_morton(stream, coords, range, n, padded, coord_bytes, codes0, ids0))) return rc;
+    if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
+    if ((rc = col_bvh_build(stream, codes1, ids1, nodes, bounds, n, coord_bytes))) return rc;
+    if ((rc = col_bvh_refit(stream, bounds, flags, coords, radii, nodes, n, coord_bytes))) return rc;
+    return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
+}
+
+}  // extern "C"

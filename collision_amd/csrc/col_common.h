@@ -1,0 +1,74 @@
+// Shared device/host helpers for libcollision_hip.so (gfx950 only: 64-lane waves).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/collision_hip.h"
+
+#define COL_WAVE 64
+
+#define COL_HIP(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return (int)e_;          \
+    } while (0)
+
+// launch check: hipGetLastError after a <<<>>> launch
+#define COL_LAUNCH_OK()                                \
+    do {                                               \
+        hipError_t e_ = hipGetLastError();             \
+        if (e_ != hipSuccess) return (int)e_;          \
+    } while (0)
+
+static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }
+
+static inline uint64_t col_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ __forceinline__ u32 lane_id() { return __lane_id(); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ u32 mbcnt(u64 mask) {
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
+// inclusive wave scan (add) via shuffles; wave = 64 lanes
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < COL_WAVE; o <<= 1) {
+        u32 t = __shfl_up(v, o, COL_WAVE);
+        if (lane >= (u32)o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int o = COL_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, COL_WAVE);
+    return v;
+}
+
+// Exclusive scan of one value per thread over a block of NT threads.
+// `warp_sums` is NT/64 words of LDS.  Returns the exclusive prefix; *total gets the block sum.
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *warp_sums, u32 *total) {
+    constexpr int NW = NT / COL_WAVE;
+    const u32 lane = lane_id(), w = threadIdx.x / COL_WAVE;
+    u32 incl = wave_incl_scan(v);
+    if (lane == COL_WAVE - 1) warp_sums[w] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        u32 s = warp_sums[i];
+        if ((u32)i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+#endif

@@ -1,0 +1,417 @@
+// Stable LSD radix sort of (key, value) pairs -- the hot loop of the path.
+// Replaces RadixSorter.sort (collision/radix.py:118-170) and its kernels block_sort / scatter
+// (collision/radix.cl:48-139).  Same result (a stable sort over ALL key bits), different shape:
+//
+//   reference, per 4-bit pass: block_sort (4 Blelloch LDS scans per block, in-place write
+//     back) -> copy -> 3..5 scan launches -> scatter -> 2 copy-backs      = 48 B/pair, 8 passes
+//   here, per 8-bit pass: k_hist (read keys) -> scan -> k_scatter (read pairs, rank in
+//     registers with wave ballots, stage through LDS, write runs)          = 20 B/pair, 4 passes
+//
+// Histogram layout is the reference's: digit-major, hist[d * nblocks + b], so one flat
+// exclusive scan yields every block's global offset per digit (radix.cl:99-100,127-136).
+//
+// k_scatter ranking (wave64): each wave owns a contiguous 64*IT slice of the tile and reads
+// it lane-striped, so (wave, item, lane) order == memory order and stability is positional.
+// For an item, the lanes holding the same digit are found with 8 __ballot()s ("match-any"),
+// a lane's rank inside that group is mbcnt(peers), and the group's lowest lane bumps a
+// wave-private LDS counter; no atomics, no cross-wave traffic until one block-wide scan of
+// the 256 digit totals.  Keys (and 4/8-byte values) are then written into LDS at their
+// tile-sorted position and streamed out so that consecutive lanes write consecutive
+// addresses inside each digit run.
+#include "col_common.h"
+
+namespace {
+
+constexpr int RT = 256;             // threads per block
+constexpr int RW = RT / COL_WAVE;   // 4 waves
+constexpr int RDIG = 256;           // 8-bit digits
+constexpr int IT = 16;              // items per thread
+constexpr int TILE = RT * IT;       // 4096 pairs per block
+constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
+
+template <int B> struct Val;
+template <> struct Val<4> { typedef uint32_t T; };
+template <> struct Val<8> { typedef uint2 T; };
+template <> struct Val<16> { typedef uint4 T; };
+struct alignas(16) V32 { uint4 a, b; };
+template <> struct Val<32> { typedef V32 T; };
+
+template <typename K> __device__ __forceinline__ u32 digit_of(K key, int shift) { return (u32)(key >> shift) & (RDIG - 1); }
+
+// lanes of this wave whose 8-bit digit equals mine
+__device__ __forceinline__ u64 match8(u32 d) {
+    u64 m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool p = (d >> b) & 1u;
+        const u64 bal = __ballot(p);
+        m &= p ? bal : ~bal;
+    }
+    return m;
+}
+
+// ---- histogram: blocks handle `g` consecutive tiles and write g-entry rows per digit ----
+template <typename K>
+__global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
+                                             int shift, u32 *__restrict__ hist) {
+    __shared__ u32 h[HG * RDIG];
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < g * RDIG; i += RT) h[i] = 0;
+    __syncthreads();
+    const u32 b0 = blockIdx.x * g;
+    for (u32 t = 0; t < g && b0 + t < nblocks; t++) {
+        const uint64_t base = (uint64_t)(b0 + t) * TILE;
+        u32 *ht = h + t * RDIG;
+        constexpr int VEC = 16 / sizeof(K);          // keys per 16-byte load
+#pragma unroll
+        for (int k = 0; k < IT / VEC; k++) {
+            const uint64_t i = base + ((uint64_t)k * RT + tid) * VEC;
+            if (i + VEC <= n) {
+                K kk[VEC];
+                *reinterpret_cast<uint4 *>(kk) = *reinterpret_cast<const uint4 *>(keys + i);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) atomicAdd(&ht[digit_of(kk[j], shift)], 1u);
+            } else {
+                for (int j = 0; j < VEC; j++)
+                    if (i + j < n) atomicAdd(&ht[digit_of(keys[i + j], shift)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // thread d writes its row of up to g entries (contiguous: full-sector writes)
+    const u32 cnt = min(g, nblocks - b0);
+    u32 *row = hist + (uint64_t)tid * nblocks + b0;
+    for (u32 t = 0; t < cnt; t++) row[t] = h[t * RDIG + tid];
+}
+
+// ---- scatter ----
+template <typename K, int VB>
+__global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+                                                const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
+                                                uint64_t n, u32 nblocks, int shift,
+                                                const u32 *__restrict__ offsets) {
+    constexpr bool HAS_V = VB > 0;
+    constexpr bool V_LDS = VB == 4 || VB == 8;       // small values are staged through LDS
+    typedef typename Val<(VB > 0 ? VB : 4)>::T V;
+    __shared__ K s_keys[TILE];
+    __shared__ V s_vals[V_LDS ? TILE : 1];
+    __shared__ u32 s_cnt[RW][RDIG];
+    __shared__ u32 s_goff[RDIG];
+    __shared__ u32 s_ws[RW];
+
+    const V *vals_in = reinterpret_cast<const V *>(vals_in_);
+    V *vals_out = reinterpret_cast<V *>(vals_out_);
+    const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
+    const u32 b = blockIdx.x;
+    const uint64_t tile_base = (uint64_t)b * TILE;
+    const u32 valid = (u32)min((uint64_t)TILE, n - tile_base);
+
+    for (u32 i = tid; i < RW * RDIG; i += RT) (&s_cnt[0][0])[i] = 0;
+
+    const u32 wbase = w * (COL_WAVE * IT) + lane;
+    K key[IT];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 li = wbase + k * COL_WAVE;
+        key[k] = li < valid ? keys_in[tile_base + li] : (K)~(K)0;   // padding sorts last, never stored
+    }
+    V val[V_LDS ? IT : 1];
+    if (V_LDS) {
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const u32 li = wbase + k * COL_WAVE;
+            if (li < valid) val[k] = vals_in[tile_base + li];
+        }
+    }
+    __syncthreads();
+
+    // rank inside (wave, digit): wave-private counters, program order keeps them consistent
+    u32 pos[IT];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 d = digit_of(key[k], shift);
+        const u64 peers = match8(d);
+        const u32 below = mbcnt(peers);
+        u32 prev = 0;
+        if (below == 0) {
+            prev = s_cnt[w][d];
+            s_cnt[w][d] = prev + (u32)__popcll(peers);
+        }
+        prev = __shfl(prev, (int)__builtin_ctzll(peers), COL_WAVE);
+        pos[k] = prev + below;
+    }
+    __syncthreads();
+
+    // digit `tid`: exclusive over waves, then exclusive over digits; fold both into s_cnt
+    {
+        const u32 c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        u32 total;
+        const u32 dstart = block_excl_scan<RT>(c0 + c1 + c2 + c3, s_ws, &total);
+        s_cnt[0][tid] = dstart;
+        s_cnt[1][tid] = dstart + c0;
+        s_cnt[2][tid] = dstart + c0 + c1;
+        s_cnt[3][tid] = dstart + c0 + c1 + c2;
+        // global position of tile-sorted slot i with digit d is s_goff[d] + i
+        s_goff[tid] = offsets[(uint64_t)tid * nblocks + b] - dstart;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 d = digit_of(key[k], shift);
+        pos[k] += s_cnt[w][d];
+        s_keys[pos[k]] = key[k];
+        if (V_LDS) s_vals[pos[k]] = val[k];
+    }
+    if (HAS_V && !V_LDS) {
+        // 16/32-byte values: each one is its own sector, scatter straight from HBM to HBM
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const u32 li = wbase + k * COL_WAVE;
+            if (li < valid) vals_out[s_goff[digit_of(key[k], shift)] + pos[k]] = vals_in[tile_base + li];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 i = k * RT + tid;
+        if (i < valid) {
+            const K kk = s_keys[i];
+            const u32 g = s_goff[digit_of(kk, shift)] + i;
+            keys_out[g] = kk;
+            if (V_LDS) vals_out[g] = s_vals[i];
+        }
+    }
+}
+
+// ---- reference-structured kernels (kernel-level parity only; one wave per block) ----
+// radix.cl:48-102 block_sort: stable sort of each block of `block` elements by the digit,
+// in place, + digit-major histogram.  Dynamic LDS: keys, values, 2^bits counters.
+template <typename K>
+__global__ __launch_bounds__(COL_WAVE) void k_ref_block_sort(K *keys, unsigned char *vals, u32 block, u32 vb,
+                                                             int bits, int pass, u32 nblocks, u32 *hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nd = 1u << bits;
+    u32 *cnt = reinterpret_cast<u32 *>(smem);
+    K *sk = reinterpret_cast<K *>(smem + ((nd * 4 + 15) & ~15u));
+    unsigned char *sv = reinterpret_cast<unsigned char *>(sk + block);
+    const u32 lane = threadIdx.x, b = blockIdx.x;
+    K *bk = keys + (uint64_t)b * block;
+    unsigned char *bv = vals ? vals + (uint64_t)b * block * vb : nullptr;
+    const int shift = pass * bits;
+    const u32 mask = nd - 1;
+    for (u32 i = lane; i < nd; i += COL_WAVE) cnt[i] = 0;
+    __syncthreads();
+    for (u32 i = lane; i < block; i += COL_WAVE) atomicAdd(&cnt[(u32)(bk[i] >> shift) & mask], 1u);
+    __syncthreads();
+    for (u32 i = lane; i < nd; i += COL_WAVE) hist[(uint64_t)i * nblocks + b] = cnt[i];
+    __syncthreads();
+    if (lane == 0) {
+        u32 acc = 0;
+        for (u32 d = 0; d < nd; d++) { const u32 c = cnt[d]; cnt[d] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (u32 c = 0; c < block; c += COL_WAVE) {
+        const u32 i = c + lane;
+        const bool act = i < block;
+        const K kk = act ? bk[i] : (K)0;
+        const u32 d = act ? ((u32)(kk >> shift) & mask) : 0xFFFFFFFFu;
+        // peers with the same digit among active lanes (digits up to 16 bits: compare via shuffles)
+        u64 peers = 0;
+        for (int l = 0; l < COL_WAVE; l++) {
+            const u32 od = __shfl(d, l, COL_WAVE);
+            if (od == d) peers |= 1ull << l;
+        }
+        if (act) {
+            const u32 below = mbcnt(peers);
+            const u32 p = cnt[d] + below;
+            sk[p] = kk;
+            if (bv) for (u32 q = 0; q < vb; q++) sv[(uint64_t)p * vb + q] = bv[(uint64_t)i * vb + q];
+        }
+        __syncthreads();
+        if (act && mbcnt(peers) == 0) cnt[d] += (u32)__popcll(peers);
+        __syncthreads();
+    }
+    for (u32 i = lane; i < block; i += COL_WAVE) bk[i] = sk[i];
+    if (bv) for (u32 i = lane; i < block * vb; i += COL_WAVE) bv[i] = sv[i];
+}
+
+// radix.cl:104-139 scatter
+template <typename K>
+__global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys_out, const unsigned char *vals,
+                                                          unsigned char *vals_out, u32 block, u32 vb, int bits,
+                                                          int pass, u32 nblocks, const u32 *offsets, const u32 *hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nd = 1u << bits;
+    u32 *loff = reinterpret_cast<u32 *>(smem);
+    u32 *lstart = loff + nd;
+    const u32 lane = threadIdx.x, b = blockIdx.x;
+    const int shift = pass * bits;
+    for (u32 i = lane; i < nd; i += COL_WAVE) {
+        loff[i] = offsets[(uint64_t)i * nblocks + b];
+        lstart[i] = hist[(uint64_t)i * nblocks + b];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        u32 acc = 0;
+        for (u32 d = 0; d < nd; d++) { const u32 c = lstart[d]; lstart[d] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (u32 i = lane; i < block; i += COL_WAVE) {
+        const uint64_t src = (uint64_t)b * block + i;
+        const K kk = keys[src];
+        const u32 d = (u32)(kk >> shift) & (nd - 1);
+        const u32 dst = loff[d] + i - lstart[d];
+        keys_out[dst] = kk;
+        if (vals && vals_out) for (u32 q = 0; q < vb; q++) vals_out[(uint64_t)dst * vb + q] = vals[src * vb + q];
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, TILE); }
+
+inline u32 hist_group(u32 nblocks) {
+    // keep >= ~1024 histogram blocks when the input allows, else fewer tiles per block
+    u32 g = HG;
+    while (g > 1 && nblocks / g < 1024) g >>= 1;
+    return g;
+}
+
+template <typename K>
+int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist) {
+    const u32 nb = tiles_of(n), g = hist_group(nb);
+    k_hist<K><<<dim3((unsigned)col_ceil_div(nb, g)), dim3(RT), 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+template <typename K>
+int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                   uint64_t n, int vb, int pass, const u32 *offsets) {
+    const u32 nb = tiles_of(n);
+    dim3 grid(nb), block(RT);
+    const K *ki = (const K *)keys;
+    K *ko = (K *)keys_out;
+    const int shift = pass * 8;
+    if (!vals || !vals_out) vb = 0;
+    switch (vb) {
+    case 0: k_scatter<K, 0><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets); break;
+    case 4: k_scatter<K, 4><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
+    case 8: k_scatter<K, 8><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
+    case 16: k_scatter<K, 16><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
+    case 32: k_scatter<K, 32><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
+    default: return COL_EINVAL;
+    }
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
+    if (key_bytes != 4 && key_bytes != 8) return true;
+    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8 && val_bytes != 16 && val_bytes != 32) return true;
+    return n >= 0xFFFFFFFFull;   // offsets are uint32 (as in the reference)
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t col_radix_tile(int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return TILE; }
+
+size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
+    const size_t nb = tiles_of(n);
+    const size_t hist = align256((size_t)RDIG * (nb ? nb : 1) * sizeof(u32));
+    return hist + align256(col_scan_scratch_bytes((uint64_t)RDIG * nb)) + align256((size_t)n * key_bytes) +
+           align256((size_t)n * val_bytes) + 256;
+}
+
+int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_bytes, int val_bytes, int pass,
+                        uint32_t *hist) {
+    if (bad_sizes(n, key_bytes, val_bytes) || pass < 0 || pass >= key_bytes) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    return key_bytes == 4 ? launch_hist<uint32_t>(col_stream(stream), keys, n, pass, hist)
+                          : launch_hist<uint64_t>(col_stream(stream), keys, n, pass, hist);
+}
+
+int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                      uint64_t n, int key_bytes, int val_bytes, int pass, const uint32_t *offsets) {
+    if (bad_sizes(n, key_bytes, val_bytes) || pass < 0 || pass >= key_bytes) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    return key_bytes == 4
+               ? launch_scatter<uint32_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets)
+               : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets);
+}
+
+int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                   uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back) {
+    if (!vals || !vals_out) val_bytes = 0;
+    if (bad_sizes(n, key_bytes, val_bytes)) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    if (!scratch) return COL_ENOSCRATCH;
+    hipStream_t s = col_stream(stream);
+    const size_t nb = tiles_of(n);
+    char *p = (char *)scratch;
+    u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
+    void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
+    void *tmp_keys = p;                p += align256((size_t)n * key_bytes);
+    void *tmp_vals = p;
+    const int passes = key_bytes;      // 8-bit digits: 4 or 8 passes (even), so the last one lands in *_out
+    const void *src_k = keys, *src_v = vals;
+    for (int pass = 0; pass < passes; pass++) {
+        void *dst_k = (pass & 1) ? keys_out : tmp_keys;
+        void *dst_v = (pass & 1) ? vals_out : tmp_vals;
+        int rc = col_radix_histogram(stream, src_k, n, key_bytes, val_bytes, pass, hist);
+        if (rc) return rc;
+        rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);
+        if (rc) return rc;
+        rc = col_radix_scatter(stream, src_k, dst_k, src_v, dst_v, n, key_bytes, val_bytes, pass, hist);
+        if (rc) return rc;
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    if (copy_back) {   // radix.py:158-169 leaves a sorted copy in the input buffers too
+        COL_HIP(hipMemcpyAsync((void *)keys, keys_out, (size_t)n * key_bytes, hipMemcpyDeviceToDevice, s));
+        if (val_bytes) COL_HIP(hipMemcpyAsync((void *)vals, vals_out, (size_t)n * val_bytes, hipMemcpyDeviceToDevice, s));
+    }
+    return COL_OK;
+}
+
+int col_ref_block_sort(void *stream, void *keys, void *vals, uint64_t n, int key_bytes, int val_bytes,
+                       uint32_t block, int bits, int pass, uint32_t *hist) {
+    if ((key_bytes != 4 && key_bytes != 8) || block == 0 || n % block || bits < 1 || bits > 12) return COL_EINVAL;
+    if (!vals) val_bytes = 0;
+    if (n == 0) return COL_OK;
+    const u32 nb = (u32)(n / block);
+    const size_t lds = (((size_t)4 << bits) + 15 & ~(size_t)15) + (size_t)block * (key_bytes + val_bytes);
+    if (lds > 64 * 1024) return COL_EINVAL;
+    if (key_bytes == 4)
+        k_ref_block_sort<uint32_t><<<dim3(nb), dim3(COL_WAVE), lds, col_stream(stream)>>>(
+            (uint32_t *)keys, (unsigned char *)vals, block, (u32)val_bytes, bits, pass, nb, hist);
+    else
+        k_ref_block_sort<uint64_t><<<dim3(nb), dim3(COL_WAVE), lds, col_stream(stream)>>>(
+            (uint64_t *)keys, (unsigned char *)vals, block, (u32)val_bytes, bits, pass, nb, hist);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_ref_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                    uint64_t n, int key_bytes, int val_bytes, uint32_t block, int bits, int pass,
+                    const uint32_t *offsets, const uint32_t *hist) {
+    if ((key_bytes != 4 && key_bytes != 8) || block == 0 || n % block || bits < 1 || bits > 12) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    const u32 nb = (u32)(n / block);
+    const size_t lds = (size_t)8 << bits;
+    if (key_bytes == 4)
+        k_ref_scatter<uint32_t><<<dim3(nb), dim3(COL_WAVE), lds, col_stream(stream)>>>(
+            (const uint32_t *)keys, (uint32_t *)keys_out, (const unsigned char *)vals, (unsigned char *)vals_out, block,
+            (u32)val_bytes, bits, pass, nb, offsets, hist);
+    else
+        k_ref_scatter<uint64_t><<<dim3(nb), dim3(COL_WAVE), lds, col_stream(stream)>>>(
+            (const uint64_t *)keys, (uint64_t *)keys_out, (const unsigned char *)vals, (unsigned char *)vals_out, block,
+            (u32)val_bytes, bits, pass, nb, offsets, hist);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// Two-stage reduction (scene bounds, sums).
+// Replaces Reducer.reduce = bounds1 + bounds2 (collision/reduce.py:62-76, collision/reduce.cl:5-58)
+// with the accumulator lists of collision/bounds.py:5 (min,max) and collision/summer.py:5 (sum).
+//
+// HBM-bound: one 16/32-byte row load per sphere.  Stage 1: grid-stride rows, register
+// accumulators, wave shuffle reduce, LDS across the block's 4 waves, one partial per block.
+// Stage 2: one block folds the partials.  min/max are exact, so the split does not matter.
+#include "col_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int RT = 256;          // threads per block
+constexpr int RMAX_BLOCKS = 1024;
+
+template <typename T, int W> struct Row { T v[W]; };
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int o) { return __shfl_xor(v, o, COL_WAVE); }
+
+template <typename T> __device__ __forceinline__ T pos_inf();
+template <> __device__ __forceinline__ float pos_inf<float>() { return INFINITY; }
+template <> __device__ __forceinline__ double pos_inf<double>() { return (double)INFINITY; }
+// integer "infinities" only matter for COL_OP_MINMAX on integer types
+template <> __device__ __forceinline__ uint32_t pos_inf<uint32_t>() { return 0xFFFFFFFFu; }
+template <> __device__ __forceinline__ int32_t pos_inf<int32_t>() { return 0x7FFFFFFF; }
+template <> __device__ __forceinline__ uint64_t pos_inf<uint64_t>() { return ~0ull; }
+template <> __device__ __forceinline__ int64_t pos_inf<int64_t>() { return 0x7FFFFFFFFFFFFFFFll; }
+template <typename T> __device__ __forceinline__ T neg_inf();
+template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+template <> __device__ __forceinline__ uint32_t neg_inf<uint32_t>() { return 0u; }
+template <> __device__ __forceinline__ int32_t neg_inf<int32_t>() { return (int32_t)0x80000000; }
+template <> __device__ __forceinline__ uint64_t neg_inf<uint64_t>() { return 0ull; }
+template <> __device__ __forceinline__ int64_t neg_inf<int64_t>() { return (int64_t)0x8000000000000000ll; }
+
+// Accumulator: A[0..NACC*W). MINMAX: [mins, maxes]; SUM: [sums].
+template <typename T, int W, int OP> struct Acc {
+    static constexpr int N = (OP == COL_OP_MINMAX ? 2 : 1) * W;
+    T a[N];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (OP == COL_OP_MINMAX) { a[i] = pos_inf<T>(); a[W + i] = neg_inf<T>(); }
+            else a[i] = (T)0;
+        }
+    }
+    __device__ __forceinline__ void add_row(const Row<T, W> &r) {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (OP == COL_OP_MINMAX) {
+                a[i] = r.v[i] < a[i] ? r.v[i] : a[i];
+                a[W + i] = r.v[i] > a[W + i] ? r.v[i] : a[W + i];
+            } else a[i] += r.v[i];
+        }
+    }
+    __device__ __forceinline__ void merge(const T *o) {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (OP == COL_OP_MINMAX) {
+                a[i] = o[i] < a[i] ? o[i] : a[i];
+                a[W + i] = o[W + i] > a[W + i] ? o[W + i] : a[W + i];
+            } else a[i] += o[i];
+        }
+    }
+    __device__ __forceinline__ void wave_reduce() {
+#pragma unroll
+        for (int o = COL_WAVE / 2; o > 0; o >>= 1) {
+            T t[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) t[i] = shfl_xor_t(a[i], o);
+            merge(t);
+        }
+    }
+};
+
+template <typename T, int W, int OP>
+__device__ __forceinline__ void block_fold(Acc<T, W, OP> &acc, T *out) {
+    constexpr int N = Acc<T, W, OP>::N;
+    __shared__ T s[(RT / COL_WAVE) * N];
+    acc.wave_reduce();
+    const u32 lane = lane_id(), w = threadIdx.x / COL_WAVE;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) s[w * N + i] = acc.a[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < RT / COL_WAVE; k++) acc.merge(&s[k * N]);
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i] = acc.a[i];
+    }
+}
+
+template <typename T, int W, int OP>
+__global__ __launch_bounds__(RT) void k_reduce1(const Row<T, W> *__restrict__ rows, uint64_t n, T *partials) {
+    Acc<T, W, OP> acc;
+    acc.init();
+    const uint64_t stride = (uint64_t)gridDim.x * RT;
+    uint64_t i = (uint64_t)blockIdx.x * RT + threadIdx.x;
+    // 4 independent rows in flight per thread
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        Row<T, W> r0 = rows[i], r1 = rows[i + stride], r2 = rows[i + 2 * stride], r3 = rows[i + 3 * stride];
+        acc.add_row(r0); acc.add_row(r1); acc.add_row(r2); acc.add_row(r3);
+    }
+    for (; i < n; i += stride) acc.add_row(rows[i]);
+    block_fold<T, W, OP>(acc, partials + (size_t)blockIdx.x * Acc<T, W, OP>::N);
+}
+
+template <typename T, int W, int OP>
+__global__ __launch_bounds__(RT) void k_reduce2(const T *partials, uint32_t nparts, T *out) {
+    constexpr int N = Acc<T, W, OP>::N;
+    Acc<T, W, OP> acc;
+    acc.init();
+    for (uint32_t i = threadIdx.x; i < nparts; i += RT) acc.merge(partials + (size_t)i * N);
+    block_fold<T, W, OP>(acc, out);
+}
+
+template <typename T, int W, int OP>
+int launch(void *stream, const void *values, uint64_t n, void *scratch, void *out) {
+    uint64_t blocks = col_ceil_div(n, (uint64_t)RT * 4);
+    if (blocks > RMAX_BLOCKS) blocks = RMAX_BLOCKS;
+    if (blocks == 0) blocks = 1;
+    k_reduce1<T, W, OP><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>(
+        (const Row<T, W> *)values, n, (T *)scratch);
+    COL_LAUNCH_OK();
+    k_reduce2<T, W, OP><<<dim3(1), dim3(RT), 0, col_stream(stream)>>>((const T *)scratch, (uint32_t)blocks, (T *)out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+template <typename T, int OP>
+int by_width(void *stream, const void *values, uint64_t n, int width, void *scratch, void *out) {
+    switch (width) {
+    case 1: return launch<T, 1, OP>(stream, values, n, scratch, out);
+    case 2: return launch<T, 2, OP>(stream, values, n, scratch, out);
+    case 4: return launch<T, 4, OP>(stream, values, n, scratch, out);
+    case 8: return launch<T, 8, OP>(stream, values, n, scratch, out);
+    case 16: return launch<T, 16, OP>(stream, values, n, scratch, out);
+    default: return COL_EINVAL;
+    }
+}
+
+template <typename T>
+int by_op(void *stream, const void *values, uint64_t n, int width, int op, void *scratch, void *out) {
+    if (op == COL_OP_MINMAX) return by_width<T, COL_OP_MINMAX>(stream, values, n, width, scratch, out);
+    if (op == COL_OP_SUM) return by_width<T, COL_OP_SUM>(stream, values, n, width, scratch, out);
+    return COL_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t col_reduce_scratch_bytes(int dtype, int width) {
+    size_t eb = (dtype == COL_F32 || dtype == COL_U32 || dtype == COL_I32) ? 4 : 8;
+    return (size_t)RMAX_BLOCKS * 2 * (size_t)width * eb;
+}
+
+int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int width, int op,
+               void *scratch, void *out) {
+    if (!scratch) return COL_ENOSCRATCH;
+    switch (dtype) {
+    case COL_F32: return by_op<float>(stream, values, n, width, op, scratch, out);
+    case COL_F64: return by_op<double>(stream, values, n, width, op, scratch, out);
+    case COL_U32: return by_op<uint32_t>(stream, values, n, width, op, scratch, out);
+    case COL_I32: return by_op<int32_t>(stream, values, n, width, op, scratch, out);
+    case COL_U64: return by_op<uint64_t>(stream, values, n, width, op, scratch, out);
+    case COL_I64: return by_op<int64_t>(stream, values, n, width, op, scratch, out);
+    default: return COL_EINVAL;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Exclusive prefix sum of uint32 (wraps mod 2^32), in place.
+// Replaces PrefixScanner.prefix_sum (collision/scan.py:75-112) and its kernels
+// local_scan / block_scan / up_sweep / down_sweep (collision/scan.cl:5-36,
+// collision/local_scan.cl:2-25).
+//
+// MI355X shape: reduce-then-scan instead of the reference's scan-then-propagate, so the
+// array is read twice and written once (12 B/element instead of 16).  A tile is 2048
+// elements per 256-thread block, 8 per thread as two 16-byte loads; inside a block the
+// per-thread totals are scanned with wave shuffles and a 4-entry LDS hand-off between
+// the block's waves (no Blelloch sweeps, no log2(n) barriers).
+#include "col_common.h"
+
+namespace {
+
+constexpr int ST = 256;              // threads per block
+constexpr int SI = 8;                // items per thread
+constexpr int STILE = ST * SI;       // 2048
+
+__device__ __forceinline__ void load_items(const u32 *data, uint64_t base, uint64_t n, u32 (&v)[SI]) {
+    // thread-blocked: 8 consecutive elements per thread, two uint4 loads when fully in range
+    if (base + SI <= n) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(data + base);
+        const uint4 b = *reinterpret_cast<const uint4 *>(data + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SI; k++) v[k] = (base + k < n) ? data[base + k] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(ST) void k_scan_reduce(const u32 *__restrict__ data, uint64_t n, u32 *__restrict__ sums) {
+    __shared__ u32 ws[ST / COL_WAVE];
+    const uint64_t base = (uint64_t)blockIdx.x * STILE + (uint64_t)threadIdx.x * SI;
+    u32 v[SI];
+    load_items(data, base, n, v);
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < SI; k++) t += v[k];
+    t = wave_sum(t);
+    if (lane_id() == 0) ws[threadIdx.x / COL_WAVE] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 s = 0;
+#pragma unroll
+        for (int i = 0; i < ST / COL_WAVE; i++) s += ws[i];
+        sums[blockIdx.x] = s;
+    }
+}
+
+// Exclusive scan of each tile, plus bases[blockIdx] when bases != NULL.
+__global__ __launch_bounds__(ST) void k_scan_apply(u32 *__restrict__ data, uint64_t n, const u32 *__restrict__ bases) {
+    __shared__ u32 ws[ST / COL_WAVE];
+    const uint64_t base = (uint64_t)blockIdx.x * STILE + (uint64_t)threadIdx.x * SI;
+    u32 v[SI];
+    load_items(data, base, n, v);
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < SI; k++) t += v[k];
+    u32 total;
+    u32 run = block_excl_scan<ST>(t, ws, &total);
+    if (bases) run += bases[blockIdx.x];
+    u32 o[SI];
+#pragma unroll
+    for (int k = 0; k < SI; k++) { o[k] = run; run += v[k]; }
+    if (base + SI <= n) {
+        *reinterpret_cast<uint4 *>(data + base) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(data + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SI; k++)
+            if (base + k < n) data[base + k] = o[k];
+    }
+}
+
+// --- the reference's two kernels with its group structure (kernel-level parity only) ---
+// scan.cl:5-30: one 64-lane wave per group of `block` elements, chunked with a carry.
+__global__ __launch_bounds__(COL_WAVE) void k_ref_local_scan(u32 *data, u32 block, u32 *block_sums) {
+    const uint64_t g0 = (uint64_t)blockIdx.x * block;
+    u32 carry = 0;
+    for (u32 c = 0; c < block; c += COL_WAVE) {
+        const u32 i = c + threadIdx.x;
+        const u32 v = i < block ? data[g0 + i] : 0u;
+        const u32 incl = wave_incl_scan(v);
+        if (i < block) data[g0 + i] = carry + incl - v;
+        carry += __shfl(incl, COL_WAVE - 1, COL_WAVE);
+    }
+    if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = carry;
+}
+
+// scan.cl:32-36
+__global__ __launch_bounds__(256) void k_ref_block_scan(u32 *data, uint64_t n, u32 block, const u32 *block_sums) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) data[i] += block_sums[i / block];
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int scan_rec(hipStream_t s, u32 *data, uint64_t n, char *scratch) {
+    if (n == 0) return COL_OK;
+    const uint64_t nb = col_ceil_div(n, STILE);
+    if (nb == 1) {
+        k_scan_apply<<<dim3(1), dim3(ST), 0, s>>>(data, n, nullptr);
+        COL_LAUNCH_OK();
+        return COL_OK;
+    }
+    u32 *sums = (u32 *)scratch;
+    k_scan_reduce<<<dim3((unsigned)nb), dim3(ST), 0, s>>>(data, n, sums);
+    COL_LAUNCH_OK();
+    int rc = scan_rec(s, sums, nb, scratch + align256(nb * sizeof(u32)));
+    if (rc) return rc;
+    k_scan_apply<<<dim3((unsigned)nb), dim3(ST), 0, s>>>(data, n, sums);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t col_scan_scratch_bytes(uint64_t n) {
+    size_t total = 256;
+    while (n > (uint64_t)STILE) {
+        n = col_ceil_div(n, STILE);
+        total += align256(n * sizeof(u32));
+    }
+    return total;
+}
+
+int col_scan_u32(void *stream, uint32_t *data, uint64_t n, void *scratch) {
+    if (n > (uint64_t)STILE && !scratch) return COL_ENOSCRATCH;
+    if (n >= ((uint64_t)1 << 42)) return COL_EINVAL;
+    return scan_rec(col_stream(stream), data, n, (char *)scratch);
+}
+
+int col_local_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, uint32_t *block_sums) {
+    if (block == 0 || n % block) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    k_ref_local_scan<<<dim3((unsigned)(n / block)), dim3(COL_WAVE), 0, col_stream(stream)>>>(data, block, block_sums);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_block_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, const uint32_t *block_sums) {
+    if (block == 0) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    k_ref_block_scan<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>(data, n, block, block_sums);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""Two-stage device reductions over rows of scalars.
+
+Mirrors ``collision/reduce.py`` (ReductionProgram :9-22, Reducer :24-76).  The reference renders
+its kernel from a Jinja2 template with a list of ``(init, fn)`` accumulators; here the two
+accumulator lists the package uses are compiled in (``COL_OP_MINMAX`` for bounds.py:5,
+``COL_OP_SUM`` for summer.py:5) and a subclass names one through ``accumulator``.
+``ngroups`` / ``group_size`` are accepted for API parity; the launch geometry is the kernel's own
+(csrc/reduce.hip) and, unlike reduce.cl:40-52, every partial is folded whatever ``ngroups`` is.
+"""
+import numpy as np
+
+from . import hip
+from ._lib import call
+from .misc import COL_OP_MINMAX, COL_OP_SUM, ProgramHandle, device_width, type_code
+
+_OPS = {
+    (("INFINITY", "min"), ("-INFINITY", "max")): COL_OP_MINMAX,
+    (("0", "ADD"),): COL_OP_SUM,
+}
+
+
+class ReductionProgram(ProgramHandle):
+    accumulator = None      # set by subclasses, as in the reference (bounds.py:5, summer.py:5)
+
+    def __init__(self, ctx, value_dtype):
+        self.value_dtype = np.dtype(value_dtype)
+        key = tuple(tuple(a) for a in (self.accumulator or ()))
+        if key not in _OPS:
+            raise ValueError("Unsupported accumulator list: {}".format(self.accumulator))
+        self.op = _OPS[key]
+        self.acc_dtype = np.dtype((self.value_dtype, len(key)))
+        self.type_code = type_code(self.value_dtype)
+        self.width = device_width(self.value_dtype)
+        super().__init__(ctx)
+
+
+class Reducer:
+    program_type = ReductionProgram
+
+    def __init__(self, ctx, ngroups, group_size, value_dtype, program=None):
+        if program is None:
+            program = self.program_type(ctx, value_dtype)
+        else:
+            if program.context != ctx:
+                raise ValueError("Collider and program context must match")
+            if program.value_dtype != np.dtype(value_dtype):
+                raise ValueError("Reducer and program value dtypes must match")
+        self.program = program
+        self.ngroups = ngroups
+        self.group_size = group_size
+        self._scratch = None          # device scratch, allocated at first use
+
+    def resize(self, ngroups=None, group_size=None):
+        if ngroups is not None:
+            self.ngroups = ngroups
+        if group_size is not None:
+            self.group_size = group_size
+
+    def reduce(self, cq, size, values_buf, output_buf, wait_for=None):
+        """Fold the first ``size`` rows of values_buf; output_buf receives one row per accumulator
+        (min row then max row for Bounds) at its start (reduce.py:62-76)."""
+        p = self.program
+        if self._scratch is None:
+            self._scratch = hip.Buffer(p.context, call.col_reduce_scratch_bytes(p.type_code, p.width))
+        cq.wait_for(wait_for)
+        call.col_reduce(cq.stream, values_buf.ptr, size, p.type_code, p.width, p.op,
+                        self._scratch.ptr, output_buf.ptr)
+        return hip.Event(cq)

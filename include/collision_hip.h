@@ -1,0 +1,185 @@
+/*
+ * collision_hip.h -- C ABI of libcollision_hip.so, the MI355X (gfx950) engine
+ * behind the kwohlfahrt/collision hot path.
+ *
+ * The reference has no FFI: its boundary is the Python class API over PyOpenCL
+ * (SURVEY.md section 8b).  Each entry point below replaces one PyOpenCL kernel
+ * enqueue (or a fixed group of them) of the reference; the reference interface
+ * it stands in for is cited as file:line relative to /root/reference.  A
+ * maintainer of the reference binds these with ctypes exactly as
+ * collision_amd/_lib.py does.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - Every function returns 0 on success, a positive hipError_t value when the
+ *     HIP runtime failed, or a negative COL_E* code; col_error_string() names it.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Every compute call is asynchronous on that stream, allocates nothing and
+ *     never synchronises; scratch comes from the caller (col_*_scratch_bytes).
+ *   - Device pointers are void* into hipMalloc'd (or torch-owned) HBM.
+ *   - coord_bytes is 4 (float) or 8 (double); a "vec3" row is 4 scalars wide
+ *     (collision/misc.py:62-71), lane w of *input* rows is ignored.
+ */
+#ifndef COLLISION_HIP_H
+#define COLLISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COL_OK 0
+#define COL_EINVAL (-1)      /* bad argument (size/dtype combination not supported) */
+#define COL_ENOSCRATCH (-2)  /* scratch pointer missing */
+
+/* element type codes for the generic reducer / fill */
+#define COL_F32 0
+#define COL_F64 1
+#define COL_U32 2
+#define COL_I32 3
+#define COL_U64 4
+#define COL_I64 5
+
+/* reduction operators (collision/bounds.py:5, collision/summer.py:5) */
+#define COL_OP_MINMAX 0   /* out = [min row, max row] */
+#define COL_OP_SUM 1      /* out = [sum row] */
+
+/* Node record, collision/collision.py:9 and collision/collision.cl:42-53. */
+typedef struct col_node {
+    uint32_t parent;      /* never written for the root */
+    uint32_t right_edge;  /* last sorted leaf position covered */
+    uint32_t data[2];     /* leaf: data[0] = sphere id; internal: children */
+} col_node;
+
+#define COL_NO_NODE 0xFFFFFFFFu   /* collision/collision.py:11 */
+
+/* ---------------------------------------------------------------- runtime
+ * Stand-ins for the PyOpenCL objects the reference's callers create
+ * (tests/conftest.py:4-12: Context/CommandQueue; cl.Buffer, cl.enqueue_copy,
+ * cl.enqueue_fill_buffer, cl.Event, cl.wait_for_events). */
+const char *col_error_string(int code);
+int col_version(void);
+int col_device_count(int *count);
+int col_set_device(int device);
+int col_get_device(int *device);
+int col_device_name(char *buf, int len);
+int col_device_sync(void);
+int col_malloc(void **ptr, size_t bytes);
+int col_free(void *ptr);
+int col_host_alloc(void **ptr, size_t bytes);   /* pinned host memory */
+int col_host_free(void *ptr);
+int col_memcpy_h2d(void *stream, void *dst, const void *src, size_t bytes);
+int col_memcpy_d2h(void *stream, void *dst, const void *src, size_t bytes);
+int col_memcpy_d2d(void *stream, void *dst, const void *src, size_t bytes);
+/* cl.enqueue_fill_buffer with a 1/2/4/8/16-byte pattern */
+int col_fill(void *stream, void *dst, const void *pattern, size_t pattern_bytes, size_t count);
+int col_stream_create(void **stream);
+int col_stream_destroy(void *stream);
+int col_stream_sync(void *stream);
+int col_stream_wait_event(void *stream, void *event);
+int col_event_create(void **event);
+int col_event_destroy(void *event);
+int col_event_record(void *event, void *stream);
+int col_event_sync(void *event);
+int col_event_elapsed_ms(float *ms, void *start, void *stop);
+
+/* ---------------------------------------------------------------- reduce
+ * Replaces Reducer.reduce = bounds1 + bounds2 (collision/reduce.py:62-76,
+ * collision/reduce.cl:5-58).  values: n rows of `width` scalars of type
+ * `dtype`; out: width mins then width maxes (COL_OP_MINMAX) or width sums. */
+size_t col_reduce_scratch_bytes(int dtype, int width);
+int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int width, int op,
+               void *scratch, void *out);
+
+/* ---------------------------------------------------------------- morton
+ * Replaces the `range` kernel, the padding fill and `calculateCodes`
+ * (collision/collision.py:137-146,161-165; collision/collision.cl:8-40).
+ * codes[i] = morton(coords[i]) for i < n, 0xFFFFFFFF for n <= i < padded;
+ * ids[i] = i for i < padded (ids may be NULL).  range = 2 rows (min, max). */
+int col_morton(void *stream, const void *coords, const void *range, uint32_t n, uint32_t padded,
+               int coord_bytes, uint32_t *codes, uint32_t *ids);
+
+/* ---------------------------------------------------------------- scan
+ * Replaces PrefixScanner.prefix_sum = local_scan/block_scan levels
+ * (collision/scan.py:75-112, collision/scan.cl:5-36): in-place exclusive
+ * scan of n uint32 (sums wrap mod 2^32). */
+size_t col_scan_scratch_bytes(uint64_t n);
+int col_scan_u32(void *stream, uint32_t *data, uint64_t n, void *scratch);
+/* The two reference kernels on their own, for the kernel-level parity tests
+ * (tests/test_scan.py:24-103): block = 2*group_size elements per group. */
+int col_local_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, uint32_t *block_sums);
+int col_block_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, const uint32_t *block_sums);
+
+/* ---------------------------------------------------------------- radix sort
+ * Replaces RadixSorter.sort (collision/radix.py:118-170): stable LSD sort of
+ * n keys (key_bytes 4|8) with optional values (val_bytes 0|4|8|16|32) over
+ * all key bits.  Result in keys_out/vals_out; keys/vals are left untouched
+ * unless copy_back != 0, which also leaves a sorted copy there as the
+ * reference does (radix.py:158-169). */
+size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes);
+int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                   uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back);
+/* One pass of the production sort, for profiling and per-pass parity:
+ * histogram (digit-major, hist[d*nblocks+b]) -> scan -> scatter. */
+uint32_t col_radix_tile(int key_bytes, int val_bytes);         /* elements per block */
+int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_bytes, int val_bytes,
+                        int pass, uint32_t *hist);
+int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                      uint64_t n, int key_bytes, int val_bytes, int pass, const uint32_t *offsets);
+/* The reference's own per-pass kernels with its block structure (block =
+ * 2*group_size, `bits` per pass, digit-major histogram), for the kernel-level
+ * parity tests (collision/radix.cl:48-139, tests/test_radix.py:61-351). */
+int col_ref_block_sort(void *stream, void *keys, void *vals, uint64_t n, int key_bytes, int val_bytes,
+                       uint32_t block, int bits, int pass, uint32_t *hist);
+int col_ref_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                    uint64_t n, int key_bytes, int val_bytes, uint32_t block, int bits, int pass,
+                    const uint32_t *offsets, const uint32_t *hist);
+
+/* ---------------------------------------------------------------- LBVH
+ * col_bvh_build replaces fillInternal + generateBVH (collision/collision.py:
+ * 171-180, collision/collision.cl:55-121): nodes[2n-1] from sorted codes/ids.
+ * If `bounds` is not NULL the traversal links are also written into the unused
+ * lane w of each node's Bound (min.w = next node when this subtree is skipped,
+ * max.w = left child or, for a leaf, the sphere id) -- see DESIGN.md. */
+int col_bvh_build(void *stream, const uint32_t *codes, const uint32_t *ids, col_node *nodes,
+                  void *bounds, uint32_t n, int coord_bytes);
+/* Replaces leafBounds + internalBounds (collision/collision.py:181-190,
+ * collision/collision.cl:128-162).  flags: 2n-1 uint32, zeroed by the caller
+ * (collision.py:147-150).  Lane w of bounds is preserved. */
+int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coords, const void *radii,
+                  const col_node *nodes, uint32_t n, int coord_bytes);
+/* Replaces traverse (collision/collision.py:191-196, collision/collision.cl:
+ * 174-226).  counter: 1 uint32 zeroed by the caller, receives the TOTAL hit
+ * count; pairs may be NULL when capacity == 0.  Needs the links written by
+ * col_bvh_build(bounds != NULL). */
+int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
+                 const col_node *nodes, const void *bounds, uint32_t n, int coord_bytes);
+
+/* ---------------------------------------------------------------- whole path
+ * Replaces Collider.get_collisions (collision/collision.py:130-198): the whole
+ * enqueue DAG as one call.  codes/ids: two buffers of `padded` uint32 each
+ * (sorted result in codes[1]/ids[1], as in the reference); nodes 2n-1;
+ * bounds (2n-1)*8 scalars; flags 2n-1 uint32; scratch from
+ * col_collide_scratch_bytes. */
+size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes);
+int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded,
+                int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
+                col_node *nodes, void *bounds, uint32_t *flags, void *scratch,
+                uint32_t *counter, uint32_t *pairs, uint32_t capacity);
+
+/* ---------------------------------------------------------------- index / offset
+ * collision/index.cl:1-13 (Indexer.gather/scatter, index.py:23-55) and
+ * collision/offset.cl:3-12 (OffsetFinder.find_offsets, offset.py:37-49). */
+int col_gather(void *stream, const void *in, const void *indices, void *out, uint64_t n,
+               int val_bytes, int index_bytes);
+int col_scatter(void *stream, const void *in, const void *indices, void *out, uint64_t n,
+                int val_bytes, int index_bytes);
+int col_find_offsets(void *stream, const void *values, uint64_t n_values, void *offsets,
+                     uint64_t n_offsets, int value_bytes, int offset_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLLISION_HIP_H */

@@ -1,0 +1,127 @@
+"""Kernel-level LBVH tests through the C ABI; mirrors tests/test_collision.py of the reference
+(test_fill_internal :50-75, test_generate_bvh :78-128, test_generate_odd_bvh :131-179,
+test_compute_bounds :182-248, test_codes :251-299, test_traverse :302-422,
+test_problem_codes :425-480)."""
+import numpy as np
+import pytest
+
+from collision_amd import hip
+from collision_amd._lib import call
+from collision_amd.collision import NO_NODE, Node
+from tests.util import download, pad4, pair_set, upload
+
+pytestmark = pytest.mark.gpu
+DTYPES = ["float32", "float64"]
+
+
+def _build(ctx, cq, codes, ids, bounds_buf=None, coord_bytes=4):
+    n = len(codes)
+    nodes_buf = upload(ctx, np.full(2 * n - 1, NO_NODE, np.uint32).repeat(4))
+    call.col_bvh_build(cq.stream, upload(ctx, codes).ptr, upload(ctx, ids).ptr, nodes_buf.ptr,
+                       None if bounds_buf is None else bounds_buf.ptr, n, coord_bytes)
+    return nodes_buf, download(cq, nodes_buf, Node, 2 * n - 1)
+
+
+def test_fill_internal(hip_env):
+    ctx, cq = hip_env
+    n = 8
+    ids = np.random.RandomState(4).permutation(n).astype(np.uint32)
+    _, nodes = _build(ctx, cq, np.arange(n, dtype=np.uint32), ids)
+    np.testing.assert_equal(nodes["data"][n - 1:, 0], ids)
+    np.testing.assert_equal(nodes["right_edge"][n - 1:], np.arange(n))
+
+
+@pytest.mark.parametrize("name", ["bvh_fig3_8", "bvh_fig3_7"])
+def test_generate_bvh(hip_env, vectors, name):
+    ctx, cq = hip_env
+    v = vectors[name]
+    codes = np.array(v["codes"], dtype=np.uint32)
+    n = len(codes)
+    _, nodes = _build(ctx, cq, codes, np.arange(n, dtype=np.uint32))
+    expected = np.array([(p, r, d) for p, r, d in v["internal"]], dtype=Node)
+    np.testing.assert_equal(nodes[1:n - 1], expected[1:])
+    np.testing.assert_equal(nodes[["data", "right_edge"]][0], expected[["data", "right_edge"]][0])
+    np.testing.assert_equal(nodes["parent"][n - 1:], v["leaf_parents"])
+    np.testing.assert_equal(nodes["right_edge"][n - 1:], np.arange(n))
+    np.testing.assert_equal(nodes["data"][n - 1:, 0], np.arange(n))
+
+
+def test_problem_codes(hip_env, vectors, oracle):
+    ctx, cq = hip_env
+    codes = np.array(vectors["problem_codes"]["codes"], dtype=np.uint32)
+    ids = np.arange(len(codes), dtype=np.uint32)
+    _, nodes = _build(ctx, cq, codes, ids)
+    assert set(nodes["parent"][1:].tolist()) == set(range(len(codes) - 1))
+    ref = oracle.build_bvh(codes, ids)
+    np.testing.assert_equal(nodes[1:len(codes) - 1], ref[1:len(codes) - 1])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_compute_bounds(hip_env, vectors, dt):
+    ctx, cq = hip_env
+    v = vectors["compute_bounds"]
+    coords = pad4(np.array(v["coords"], dtype=dt))
+    radii = np.array(v["radii"], dtype=dt)
+    nodes = np.array([(p, r, d) for p, r, d in v["nodes"]], dtype=Node)
+    bounds_buf = hip.Buffer(ctx, len(nodes) * 8 * np.dtype(dt).itemsize)
+    flags_buf = upload(ctx, np.zeros(len(nodes), np.uint32))
+    call.col_bvh_refit(cq.stream, bounds_buf.ptr, flags_buf.ptr, upload(ctx, coords).ptr, upload(ctx, radii).ptr,
+                       upload(ctx, nodes).ptr, len(coords), np.dtype(dt).itemsize)
+    bounds = download(cq, bounds_buf, dt, (len(nodes), 2, 4))
+    np.testing.assert_equal(bounds[:, :, :3], np.array(v["expected"], dtype=dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_codes(hip_env, vectors, dt):
+    ctx, cq = hip_env
+    v = vectors["morton_codes"]
+    coords = np.array(v["coords"], dtype=dt)
+    rng = pad4(np.array([coords.min(axis=0), coords.max(axis=0)]))
+    codes_buf, ids_buf = hip.Buffer(ctx, 16 * 4), hip.Buffer(ctx, 16 * 4)
+    call.col_morton(cq.stream, upload(ctx, pad4(coords)).ptr, upload(ctx, rng).ptr, 6, 16, np.dtype(dt).itemsize,
+                    codes_buf.ptr, ids_buf.ptr)
+    codes = download(cq, codes_buf, np.uint32)
+    np.testing.assert_equal(codes[:6], np.array(v["expected"], dtype=np.uint32))
+    assert (codes[6:] == 0xFFFFFFFF).all()                          # collision.py:137-142
+    np.testing.assert_equal(download(cq, ids_buf, np.uint32), np.arange(16))   # collision.cl:8-10
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_traverse(hip_env, vectors, dt):
+    """The whole kernel chain with a host argsort in place of the radix sort (test_collision.py:302-422)."""
+    ctx, cq = hip_env
+    v = vectors["six_sphere_scene"]
+    cb = np.dtype(dt).itemsize
+    coords = np.array(v["coords"], dtype=dt)
+    radii = np.array(v["radii"], dtype=dt)
+    n = len(coords)
+    coords_buf, radii_buf = upload(ctx, pad4(coords)), upload(ctx, radii)
+    rng = pad4(np.array([coords.min(axis=0), coords.max(axis=0)]))
+    codes_buf = hip.Buffer(ctx, n * 4)
+    call.col_morton(cq.stream, coords_buf.ptr, upload(ctx, rng).ptr, n, n, cb, codes_buf.ptr, None)
+    codes = download(cq, codes_buf, np.uint32)
+    order = np.argsort(codes, kind="mergesort").astype(np.uint32)
+    bounds_buf = hip.Buffer(ctx, (2 * n - 1) * 8 * cb)
+    nodes_buf, _ = _build(ctx, cq, codes[order], order, bounds_buf, cb)
+    flags_buf = upload(ctx, np.zeros(2 * n - 1, np.uint32))
+    call.col_bvh_refit(cq.stream, bounds_buf.ptr, flags_buf.ptr, coords_buf.ptr, radii_buf.ptr, nodes_buf.ptr, n, cb)
+    pairs_buf = upload(ctx, np.full(4, 0xFFFFFFFF, np.uint32))
+    count_buf = upload(ctx, np.zeros(1, np.uint32))
+    call.col_traverse(cq.stream, pairs_buf.ptr, count_buf.ptr, 2, nodes_buf.ptr, bounds_buf.ptr, n, cb)
+    assert download(cq, count_buf, np.uint32)[0] == 2
+    assert pair_set(download(cq, pairs_buf, np.uint32, (2, 2))) == pair_set(v["expected_pairs"])
+
+
+def test_random_trees_match_oracle(hip_env, oracle):
+    """Karras topology on random sorted codes with many duplicates, several sizes."""
+    ctx, cq = hip_env
+    rs = np.random.RandomState(4)
+    for n, hi in ((2, 4), (3, 2), (17, 8), (1000, 300), (5000, 2 ** 30), (65537, 50000)):
+        codes = np.sort(rs.randint(0, hi, size=n).astype(np.uint32))
+        ids = rs.permutation(n).astype(np.uint32)
+        _, nodes = _build(ctx, cq, codes, ids)
+        ref = oracle.build_bvh(codes, ids)
+        np.testing.assert_equal(nodes["right_edge"], ref["right_edge"])
+        np.testing.assert_equal(nodes["parent"][1:], ref["parent"][1:])
+        np.testing.assert_equal(nodes["data"][:n - 1], ref["data"][:n - 1])
+        np.testing.assert_equal(nodes["data"][n - 1:, 0], ref["data"][n - 1:, 0])

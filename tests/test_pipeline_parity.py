@@ -1,0 +1,166 @@
+"""Bit-exact parity of every intermediate of the path against the CPU oracle, through the C ABI.
+
+sorted Morton keys / ids, Node records, node AABBs and the emitted pair set (with orientation)
+must equal the oracle's on the same seeded inputs (BASELINE.json north_star).  Also the
+size-independent properties at full size: sortedness, permutation, tree invariants, count vs
+count-only, pairs verified box-by-box.
+"""
+import numpy as np
+import pytest
+
+from collision_amd.collision import NO_NODE, Collider
+from tests.util import collider_state, pad4, pair_set, run_collider
+
+pytestmark = pytest.mark.gpu
+
+
+def uniform_scene(n, r, dtype, seed=4):
+    rng = np.random.RandomState(seed)
+    coords = rng.random_sample((n, 3)).astype(dtype)
+    return coords, np.full(n, r, dtype=dtype)
+
+
+def clustered_scene(n, sigma, r, dtype, seed=4):
+    rng = np.random.RandomState(seed)
+    centres = rng.uniform(0.2, 0.8, size=(8, 3))
+    pts = np.concatenate([rng.normal(c, sigma, size=(n // 8, 3)) for c in centres])
+    pts = np.concatenate([pts, rng.normal(centres[0], sigma, size=(n - len(pts), 3))])
+    return pts.astype(dtype), np.full(n, r, dtype=dtype)
+
+
+def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=8, capacity=None):
+    ctx, cq = hip_env
+    dt = coords.dtype
+    n = len(coords)
+    collider = Collider(ctx, n, ngroups, group_size, dt)
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size,
+                         capacity=capacity if capacity is not None else 64 * n)
+    cap = ref["count"] if capacity is None else capacity
+    count, pairs = run_collider(ctx, cq, collider, coords, radii, cap)
+    st = collider_state(cq, collider)
+    np.testing.assert_array_equal(st["codes"], ref["codes"])
+    np.testing.assert_array_equal(st["ids"], ref["ids"])
+    leaf = n - 1
+    np.testing.assert_array_equal(st["nodes"]["right_edge"], ref["nodes"]["right_edge"])
+    np.testing.assert_array_equal(st["nodes"]["parent"][1:], ref["nodes"]["parent"][1:])   # root parent unwritten
+    np.testing.assert_array_equal(st["nodes"]["data"][:leaf], ref["nodes"]["data"][:leaf])
+    np.testing.assert_array_equal(st["nodes"]["data"][leaf:, 0], ref["nodes"]["data"][leaf:, 0])
+    np.testing.assert_array_equal(st["bounds"][:, :, :3], ref["bounds"][:, :, :3])
+    assert count == ref["count"]
+    if capacity is None:
+        assert pair_set(pairs) == pair_set(ref["pairs"])       # same orientation, any order
+        assert len(pairs) == len(pair_set(pairs))
+    return collider, st, count, pairs
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n,r,gs", [(2, 0.6, 8), (3, 0.3, 8), (7, 0.3, 8), (64, 0.1, 32), (1000, 0.03, 64),
+                                    (4099, 0.01, 128), (100000, 0.003, 256)])
+def test_uniform_scene_matches_oracle(oracle, hip_env, dtype, n, r, gs):
+    coords, radii = uniform_scene(n, r, dtype)
+    check_against_oracle(oracle, hip_env, coords, radii, group_size=gs)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_clustered_scene_matches_oracle(oracle, hip_env, dtype):
+    coords, radii = clustered_scene(20000, 0.01, 0.002, dtype)
+    _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256)
+    assert count > 20000          # a dense scene: many contacts per sphere
+
+
+def test_duplicate_centres_and_equal_codes(oracle, hip_env):
+    # equal Morton codes fall back to the index tie-break (collision.cl:74-76); stability of the
+    # sort decides which id lands where (tests/test_radix_py.py:201)
+    rng = np.random.RandomState(4)
+    base = rng.random_sample((50, 3)).astype("float32")
+    coords = np.repeat(base, 40, axis=0)
+    rng.shuffle(coords)
+    radii = np.full(len(coords), 1e-4, dtype="float32")
+    check_against_oracle(oracle, hip_env, coords, radii, group_size=64)
+
+
+def test_all_spheres_identical(oracle, hip_env):
+    # max == min on every axis: 0/0 -> NaN -> code 0 for everybody
+    coords = np.full((300, 3), 0.25, dtype="float32")
+    radii = np.full(300, 0.1, dtype="float32")
+    _, st, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=32)
+    assert count == 300 * 299 // 2 and (st["codes"][:300] == 0).all()
+
+
+def test_degenerate_axis(oracle, hip_env):
+    coords, radii = uniform_scene(2000, 0.02, "float32")
+    coords[:, 2] = 0.5
+    check_against_oracle(oracle, hip_env, coords, radii)
+
+
+def test_touching_boxes_do_not_collide(oracle, hip_env):
+    # strict inequalities (collision.cl:164-166): faces that touch exactly are not an overlap
+    coords = np.array([[0, 0, 0], [2, 0, 0], [4, 0, 0], [4, 1.5, 0]], dtype="float32")
+    radii = np.ones(4, dtype="float32")
+    _, _, count, pairs = check_against_oracle(oracle, hip_env, coords, radii, group_size=8)
+    assert count == 1 and pair_set(np.sort(pairs, axis=1)) == {(2, 3)}
+
+
+def test_varied_radii_negative_coords(oracle, hip_env):
+    rng = np.random.RandomState(4)
+    coords = rng.uniform(-1, 1, size=(30000, 3)).astype("float32")     # tests/benchmarks/test_collide.py:24-30
+    radii = rng.uniform(0.006, 0.06, size=30000).astype("float32")
+    check_against_oracle(oracle, hip_env, coords, radii, group_size=128)
+
+
+def test_capacity_overflow_counts_everything(oracle, hip_env):
+    coords, radii = uniform_scene(5000, 0.02, "float32")
+    _, _, count, pairs = check_against_oracle(oracle, hip_env, coords, radii, capacity=100)
+    assert count > 100 and len(pairs) == 100
+
+
+def test_config2_full_size_properties(hip_env):
+    """BASELINE config 2 (1M uniform, r=0.001) at full size, checked through properties the
+    domain offers (the oracle run at this size lives in bench.py's cpu_baseline leg)."""
+    ctx, cq = hip_env
+    n = 1000000
+    coords, radii = uniform_scene(n, 0.001, "float32")
+    collider = Collider(ctx, n, 64, 256, "float32")
+    count, pairs = run_collider(ctx, cq, collider, coords, radii, 1 << 17)
+    st = collider_state(cq, collider)
+    codes, ids, nodes, bounds = st["codes"], st["ids"], st["nodes"], st["bounds"]
+    # sortedness + permutation + padding (collision.py:137-146)
+    assert (np.diff(codes.astype(np.int64)) >= 0).all()
+    assert (codes[n:] == 0xFFFFFFFF).all() and (ids[n:] == np.arange(n, collider.padded_size)).all()
+    assert (np.sort(ids[:n]) == np.arange(n)).all()
+    eq = codes[1:n] == codes[:n - 1]
+    assert (ids[1:n][eq] > ids[:n - 1][eq]).all()                     # stability
+    # codes are the Morton codes of the spheres they travel with
+    rng_ = np.stack([coords.min(axis=0), coords.max(axis=0)])
+    q = np.clip(((coords - rng_[0]) / (rng_[1] - rng_[0])) * np.float32(1023), 0, 1023).astype(np.uint32)
+
+    def expand(v):
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        return (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+    expect = (expand(q[:, 0]) << 2) + (expand(q[:, 1]) << 1) + expand(q[:, 2])
+    np.testing.assert_array_equal(codes[:n], expect[ids[:n]])
+    # tree invariants: every internal node is the parent of exactly its two children
+    leaf = n - 1
+    kids = nodes["data"][:leaf]
+    assert (nodes["parent"][kids[:, 0]] == np.arange(leaf)).all()
+    assert (nodes["parent"][kids[:, 1]] == np.arange(leaf)).all()
+    assert len(np.unique(kids)) == 2 * leaf and nodes["right_edge"][0] == n - 1
+    # a parent's box is exactly the union of its children's; the root's is the scene's
+    np.testing.assert_array_equal(bounds[:leaf, 0, :3], np.minimum(bounds[kids[:, 0], 0, :3], bounds[kids[:, 1], 0, :3]))
+    np.testing.assert_array_equal(bounds[:leaf, 1, :3], np.maximum(bounds[kids[:, 0], 1, :3], bounds[kids[:, 1], 1, :3]))
+    np.testing.assert_array_equal(bounds[0, 0, :3], (coords - radii[:, None]).min(axis=0))
+    # every reported pair really overlaps, is unique, and is oriented by sorted position
+    assert count == len(pairs) and len(pair_set(pairs)) == count
+    lo, hi = coords - radii[:, None], coords + radii[:, None]
+    a, b = pairs[:, 0], pairs[:, 1]
+    assert ((hi[a] > lo[b]) & (lo[a] < hi[b])).all()
+    pos = np.empty(n, np.int64)
+    pos[ids[:n]] = np.arange(n)
+    assert (pos[a] < pos[b]).all()
+    # count-only mode agrees
+    count2, _ = run_collider(ctx, cq, collider, coords, radii, 0)
+    assert count2 == count
+    # expected number of AABB contacts for uniform points: n^2/2 * (4r)^3 within a few percent
+    assert abs(count - n * n / 2 * (4 * 0.001) ** 3) < 0.1 * count

@@ -1,0 +1,120 @@
+"""Kernel-level radix tests through the C ABI.
+
+(a) the reference's own per-pass structure -- block_sort / scatter with block = 2*group_size and a
+    digit-major histogram (tests/test_radix.py:61-351) -- via col_ref_block_sort / col_ref_scatter;
+(b) the production pass -- col_radix_histogram -> col_scan_u32 -> col_radix_scatter -- checked
+    per pass against a stable argsort by the digit, and its histogram against bincount per tile.
+"""
+import numpy as np
+import pytest
+
+from collision_amd import hip
+from collision_amd._lib import call
+from tests.util import download, upload
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 8), (3, 8), (4, 8), (8, 32), (16, 128)]
+
+
+def radix_key(values, bits, rpass):           # tests/test_radix.py:56-57
+    return (values >> np.array(rpass * bits, values.dtype)) & np.array((1 << bits) - 1, values.dtype)
+
+
+def excl(x):                                  # tests/test_radix.py:27-30
+    r = np.zeros_like(x)
+    r[1:] = np.cumsum(x)[:-1]
+    return r
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("ngroups,group_size", SIZES)
+def test_ref_block_sort_and_scatter(hip_env, oracle, key_dtype, ngroups, group_size):
+    ctx, cq = hip_env
+    bits, block = 4, 2 * group_size
+    kb = np.dtype(key_dtype).itemsize
+    rs = np.random.RandomState(4)
+    keys = rs.randint(0, 64, size=ngroups * block).astype(key_dtype)
+    hist_buf = hip.Buffer(ctx, 16 * ngroups * 4)
+    for rpass in range(kb * 8 // bits):
+        keys_buf = upload(ctx, keys)
+        call.col_ref_block_sort(cq.stream, keys_buf.ptr, None, len(keys), kb, 0, block, bits, rpass, hist_buf.ptr)
+        got_keys = download(cq, keys_buf, key_dtype)
+        got_hist = download(cq, hist_buf, np.uint32, (16, ngroups))
+        exp_keys, _, exp_hist = oracle.block_sort(keys, None, block, bits, rpass)
+        np.testing.assert_array_equal(got_keys, exp_keys)
+        np.testing.assert_array_equal(got_hist, exp_hist)
+        digit = radix_key(keys.reshape(ngroups, block), bits, rpass)
+        order = np.argsort(digit, kind="mergesort", axis=1)
+        np.testing.assert_array_equal(got_keys.reshape(ngroups, block),
+                                      np.take_along_axis(keys.reshape(ngroups, block), order, axis=1))
+        offs = excl(got_hist.reshape(-1)).astype(np.uint32)
+        out_buf = hip.Buffer(ctx, keys.nbytes)
+        offs_buf = upload(ctx, offs)
+        call.col_ref_scatter(cq.stream, keys_buf.ptr, out_buf.ptr, None, None, len(keys), kb, 0, block, bits, rpass,
+                             offs_buf.ptr, hist_buf.ptr)
+        out = download(cq, out_buf, key_dtype)
+        np.testing.assert_array_equal(out, keys[np.argsort(radix_key(keys, bits, rpass), kind="mergesort")])
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("value_dtype", ["uint32", "float64"])
+@pytest.mark.parametrize("ngroups,group_size", SIZES)
+def test_ref_argsort_loop(hip_env, key_dtype, value_dtype, ngroups, group_size):
+    # tests/test_radix.py:249-351: the whole multi-pass loop with a host-side scan, checked after every pass
+    ctx, cq = hip_env
+    bits, block = 4, 2 * group_size
+    kb, vb = np.dtype(key_dtype).itemsize, np.dtype(value_dtype).itemsize
+    rs = np.random.RandomState(4)
+    keys = rs.randint(0, 64, size=ngroups * block).astype(key_dtype)
+    values = rs.uniform(-1000, 1000, size=len(keys)).astype(value_dtype)
+    sort_keys, sort_values = keys, values
+    keys_buf, vals_buf = upload(ctx, keys), upload(ctx, values)
+    out_k, out_v = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, values.nbytes)
+    hist_buf, offs_buf = hip.Buffer(ctx, 16 * ngroups * 4), hip.Buffer(ctx, 16 * ngroups * 4)
+    for rpass in range(kb * 8 // bits):
+        call.col_ref_block_sort(cq.stream, keys_buf.ptr, vals_buf.ptr, len(keys), kb, vb, block, bits, rpass, hist_buf.ptr)
+        hist = download(cq, hist_buf, np.uint32)
+        hip.write_buffer(cq, offs_buf, excl(hist).astype(np.uint32))
+        call.col_ref_scatter(cq.stream, keys_buf.ptr, out_k.ptr, vals_buf.ptr, out_v.ptr, len(keys), kb, vb, block,
+                             bits, rpass, offs_buf.ptr, hist_buf.ptr)
+        hip.enqueue_copy(cq, keys_buf, out_k)
+        hip.enqueue_copy(cq, vals_buf, out_v)
+        order = np.argsort(radix_key(sort_keys, bits, rpass), kind="mergesort")
+        sort_keys, sort_values = sort_keys[order], sort_values[order]
+        np.testing.assert_array_equal(download(cq, keys_buf, key_dtype), sort_keys)
+        np.testing.assert_array_equal(download(cq, vals_buf, value_dtype), sort_values)
+    order = np.argsort(keys, kind="mergesort")
+    np.testing.assert_array_equal(download(cq, keys_buf, key_dtype), keys[order])
+    np.testing.assert_array_equal(download(cq, vals_buf, value_dtype), values[order])
+
+
+@pytest.mark.parametrize("key_dtype,val_bytes", [("uint32", 0), ("uint32", 4), ("uint32", 8), ("uint64", 4),
+                                                 ("uint64", 16), ("uint32", 32)])
+@pytest.mark.parametrize("n", [5000, 70001])
+def test_production_pass(hip_env, key_dtype, val_bytes, n):
+    ctx, cq = hip_env
+    kb = np.dtype(key_dtype).itemsize
+    tile = call.col_radix_tile(kb, val_bytes)
+    nblocks = -(-n // tile)
+    rs = np.random.RandomState(4)
+    keys = (rs.randint(0, 2 ** 32, size=n, dtype=np.uint64) * np.uint64(2654435761)).astype(key_dtype)
+    vals = rs.randint(0, 255, size=(n, max(val_bytes, 1))).astype(np.uint8)
+    keys_buf, vals_buf = upload(ctx, keys), upload(ctx, vals)
+    out_k, out_v = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+    hist_buf = hip.Buffer(ctx, 256 * nblocks * 4)
+    scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nblocks))
+    for rpass in range(kb):
+        call.col_radix_histogram(cq.stream, keys_buf.ptr, n, kb, val_bytes, rpass, hist_buf.ptr)
+        hist = download(cq, hist_buf, np.uint32, (256, nblocks))
+        digit = radix_key(keys, 8, rpass).astype(np.int64)
+        for b in range(nblocks):                    # digit-major layout, radix.cl:99-100
+            np.testing.assert_array_equal(hist[:, b], np.bincount(digit[b * tile:(b + 1) * tile], minlength=256))
+        call.col_scan_u32(cq.stream, hist_buf.ptr, 256 * nblocks, scratch.ptr)
+        np.testing.assert_array_equal(download(cq, hist_buf, np.uint32), excl(hist.reshape(-1)))
+        call.col_radix_scatter(cq.stream, keys_buf.ptr, out_k.ptr, vals_buf.ptr if val_bytes else None,
+                               out_v.ptr if val_bytes else None, n, kb, val_bytes, rpass, hist_buf.ptr)
+        order = np.argsort(digit, kind="stable")
+        np.testing.assert_array_equal(download(cq, out_k, key_dtype), keys[order])
+        if val_bytes:
+            np.testing.assert_array_equal(download(cq, out_v, np.uint8, vals.shape), vals[order])

@@ -1,0 +1,157 @@
+"""RadixSorter on the GPU; mirrors tests/test_radix_py.py:83-201 (test_sorter, test_sorter_resized,
+test_arg_sorter) and adds the BASELINE config-5 key distributions at larger sizes."""
+import numpy as np
+import pytest
+
+from collision_amd import hip
+from collision_amd.radix import PrefixScanProgram, RadixProgram, RadixSorter
+from tests.util import download, upload
+
+pytestmark = pytest.mark.gpu
+
+VALUE_DTYPES = [np.dtype("uint32"), np.dtype("float64"), np.dtype(("float64", 3)), np.dtype(("float64", 4)),
+                np.dtype(("float32", 3))]
+
+
+def _sort(ctx, cq, sorter, keys, values=None, value_dtype=None):
+    keys_buf = upload(ctx, keys)
+    out_keys = hip.Buffer(ctx, keys.nbytes)
+    if values is None:
+        e = sorter.sort(cq, keys_buf, out_keys)
+        return download(cq, out_keys, keys.dtype, keys.shape, wait_for=[e]), None, download(cq, keys_buf, keys.dtype)
+    if value_dtype.shape == (3,):                       # vec3 values are 4 wide on the device
+        dev = np.zeros((len(values), 4), dtype=values.dtype)
+        dev[:, :3] = values
+    else:
+        dev = values
+    vals_buf = upload(ctx, dev)
+    out_vals = hip.Buffer(ctx, dev.nbytes)
+    e = sorter.sort(cq, keys_buf, out_keys, vals_buf, out_vals)
+    k = download(cq, out_keys, keys.dtype, keys.shape, wait_for=[e])
+    v = download(cq, out_vals, dev.dtype, dev.shape)
+    if value_dtype.shape == (3,):
+        v = v[:, :3]
+    return k, v, download(cq, keys_buf, keys.dtype)
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("size,group_size", [(32, 8), (15360, 32), (32, 16)])
+def test_sorter(hip_env, key_dtype, size, group_size):
+    ctx, cq = hip_env
+    sorter = RadixSorter(ctx, size, group_size, key_dtype=key_dtype, program=RadixProgram(ctx, key_dtype),
+                         scan_program=PrefixScanProgram(ctx))
+    data = np.random.RandomState(4).randint(500, size=size).astype(key_dtype)
+    out, _, untouched = _sort(ctx, cq, sorter, data)
+    np.testing.assert_equal(out, np.sort(data))
+    np.testing.assert_equal(untouched, data)            # inputs are left alone (see radix.py docstring)
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("old_shape,new_shape", [((15360, 32), (32, 8)), ((32, 8), (15360, 32))])
+def test_sorter_resized(hip_env, key_dtype, old_shape, new_shape):
+    ctx, cq = hip_env
+    sorter = RadixSorter(ctx, *old_shape, key_dtype=key_dtype, program=RadixProgram(ctx, key_dtype))
+    rs = np.random.RandomState(4)
+    _sort(ctx, cq, sorter, rs.randint(500, size=old_shape[0]).astype(key_dtype))
+    sorter.resize(*new_shape)
+    data = rs.randint(500, size=new_shape[0]).astype(key_dtype)
+    out, _, _ = _sort(ctx, cq, sorter, data)
+    np.testing.assert_equal(out, np.sort(data))
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("value_dtype", VALUE_DTYPES, ids=str)
+@pytest.mark.parametrize("size,group_size", [(32, 8), (15360, 32)])
+def test_arg_sorter(hip_env, key_dtype, value_dtype, size, group_size):
+    ctx, cq = hip_env
+    sorter = RadixSorter(ctx, size, group_size, key_dtype=key_dtype, value_dtype=value_dtype,
+                         program=RadixProgram(ctx, key_dtype, value_dtype))
+    rs = np.random.RandomState(4)
+    keys = rs.randint(500, size=size).astype(key_dtype)
+    values = rs.uniform(-1000, 1000, size=(size,) + value_dtype.shape).astype(value_dtype.base)
+    k, v, _ = _sort(ctx, cq, sorter, keys, values, value_dtype)
+    np.testing.assert_equal(k, np.sort(keys))
+    np.testing.assert_equal(v, values[np.argsort(keys, kind="mergesort")])       # stability
+
+
+def test_keep_sorted_inputs_matches_reference_postcondition(hip_env):
+    # radix.py:158-169: after sort() the reference's input buffers hold the sorted data too
+    ctx, cq = hip_env
+    sorter = RadixSorter(ctx, 4096, 64)
+    sorter.keep_sorted_inputs = True
+    rs = np.random.RandomState(4)
+    keys = rs.randint(0, 2 ** 32, size=4096, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(4096, dtype=np.uint32)
+    keys_buf, vals_buf = upload(ctx, keys), upload(ctx, vals)
+    out_k, out_v = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+    e = sorter.sort(cq, keys_buf, out_k, vals_buf, out_v)
+    order = np.argsort(keys, kind="mergesort")
+    for buf, expect in ((keys_buf, keys[order]), (out_k, keys[order]), (vals_buf, vals[order]), (out_v, vals[order])):
+        np.testing.assert_equal(download(cq, buf, np.uint32, wait_for=[e]), expect)
+
+
+def _config5_keys(kind, n, dtype):
+    rs = np.random.RandomState(4)
+    if kind == "morton30":
+        return rs.randint(0, 2 ** 30, size=n).astype(dtype)
+    if kind == "full":
+        bits = 8 * np.dtype(dtype).itemsize
+        return rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(dtype) if bits == 32 else \
+            (rs.randint(0, 2 ** 32, size=n, dtype=np.uint64) << np.uint64(32) | rs.randint(0, 2 ** 32, size=n, dtype=np.uint64))
+    if kind == "arange":
+        return np.arange(n, dtype=dtype)
+    if kind == "reversed":
+        return np.arange(n, dtype=dtype)[::-1].copy()
+    if kind == "few":
+        return rs.randint(0, 1000, size=n).astype(dtype)       # tests/benchmarks/test_radix.py:51-55
+    if kind == "constant":
+        return np.full(n, 0xDEADBEEF, dtype=dtype)
+    if kind == "allones":
+        return np.full(n, np.iinfo(dtype).max, dtype=dtype)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("key_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("kind", ["morton30", "full", "arange", "reversed", "few", "constant", "allones"])
+@pytest.mark.parametrize("size,group_size", [(307200, 128), (1000448, 256)])
+def test_key_distributions_with_ids(hip_env, key_dtype, kind, size, group_size):
+    ctx, cq = hip_env
+    sorter = RadixSorter(ctx, size, group_size, key_dtype=key_dtype, program=RadixProgram(ctx, key_dtype))
+    keys = _config5_keys(kind, size, key_dtype)
+    vals = np.arange(size, dtype=np.uint32)
+    k, v, _ = _sort(ctx, cq, sorter, keys, vals, np.dtype("uint32"))
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(k, keys[order])
+    np.testing.assert_array_equal(v, order.astype(np.uint32))
+
+
+def test_large_sort_properties(hip_env):
+    """16 Mi random 32-bit keys + ids: sortedness, permutation, stability, key/value pairing."""
+    ctx, cq = hip_env
+    n = 1 << 24
+    sorter = RadixSorter(ctx, n, 256)
+    keys = np.random.RandomState(4).randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    k, v, _ = _sort(ctx, cq, sorter, keys, np.arange(n, dtype=np.uint32), np.dtype("uint32"))
+    assert (np.diff(k.astype(np.int64)) >= 0).all()
+    np.testing.assert_array_equal(keys[v], k)
+    eq = k[1:] == k[:-1]
+    assert (v[1:][eq] > v[:-1][eq]).all()
+    assert (np.bincount(v, minlength=n) == 1).all()
+
+
+def test_sizes_around_the_tile(hip_env):
+    """The C ABI takes any n (the 2*group_size rule is the Python class's); ragged tails."""
+    from collision_amd._lib import call
+    ctx, cq = hip_env
+    tile = call.col_radix_tile(4, 4)
+    rs = np.random.RandomState(4)
+    for n in (1, 2, 63, 64, 65, tile - 1, tile, tile + 1, 3 * tile + 17):
+        keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = upload(ctx, keys), upload(ctx, vals)
+        ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+        scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+        call.col_radix_sort(cq.stream, kb.ptr, ko.ptr, vb.ptr, vo.ptr, n, 4, 4, scratch.ptr, 0)
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
+        np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
