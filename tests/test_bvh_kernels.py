@@ -17,7 +17,8 @@ DTYPES = ["float32", "float64"]
 def _build(ctx, cq, codes, ids, bounds_buf=None, coord_bytes=4):
     n = len(codes)
     nodes_buf = upload(ctx, np.full(2 * n - 1, NO_NODE, np.uint32).repeat(4))
-    call.col_bvh_build(cq.stream, upload(ctx, codes).ptr, upload(ctx, ids).ptr, nodes_buf.ptr,
+    codes_buf, ids_buf = upload(ctx, codes), upload(ctx, ids)      # keep alive until the read-back
+    call.col_bvh_build(cq.stream, codes_buf.ptr, ids_buf.ptr, nodes_buf.ptr,
                        None if bounds_buf is None else bounds_buf.ptr, n, coord_bytes)
     return nodes_buf, download(cq, nodes_buf, Node, 2 * n - 1)
 
@@ -65,8 +66,9 @@ def test_compute_bounds(hip_env, vectors, dt):
     nodes = np.array([(p, r, d) for p, r, d in v["nodes"]], dtype=Node)
     bounds_buf = hip.Buffer(ctx, len(nodes) * 8 * np.dtype(dt).itemsize)
     flags_buf = upload(ctx, np.zeros(len(nodes), np.uint32))
-    call.col_bvh_refit(cq.stream, bounds_buf.ptr, flags_buf.ptr, upload(ctx, coords).ptr, upload(ctx, radii).ptr,
-                       upload(ctx, nodes).ptr, len(coords), np.dtype(dt).itemsize)
+    coords_buf, radii_buf, nodes_buf = upload(ctx, coords), upload(ctx, radii), upload(ctx, nodes)
+    call.col_bvh_refit(cq.stream, bounds_buf.ptr, flags_buf.ptr, coords_buf.ptr, radii_buf.ptr,
+                       nodes_buf.ptr, len(coords), np.dtype(dt).itemsize)
     bounds = download(cq, bounds_buf, dt, (len(nodes), 2, 4))
     np.testing.assert_equal(bounds[:, :, :3], np.array(v["expected"], dtype=dt))
 
@@ -78,7 +80,8 @@ def test_codes(hip_env, vectors, dt):
     coords = np.array(v["coords"], dtype=dt)
     rng = pad4(np.array([coords.min(axis=0), coords.max(axis=0)]))
     codes_buf, ids_buf = hip.Buffer(ctx, 16 * 4), hip.Buffer(ctx, 16 * 4)
-    call.col_morton(cq.stream, upload(ctx, pad4(coords)).ptr, upload(ctx, rng).ptr, 6, 16, np.dtype(dt).itemsize,
+    coords_buf, rng_buf = upload(ctx, pad4(coords)), upload(ctx, rng)
+    call.col_morton(cq.stream, coords_buf.ptr, rng_buf.ptr, 6, 16, np.dtype(dt).itemsize,
                     codes_buf.ptr, ids_buf.ptr)
     codes = download(cq, codes_buf, np.uint32)
     np.testing.assert_equal(codes[:6], np.array(v["expected"], dtype=np.uint32))
@@ -97,8 +100,8 @@ def test_traverse(hip_env, vectors, dt):
     n = len(coords)
     coords_buf, radii_buf = upload(ctx, pad4(coords)), upload(ctx, radii)
     rng = pad4(np.array([coords.min(axis=0), coords.max(axis=0)]))
-    codes_buf = hip.Buffer(ctx, n * 4)
-    call.col_morton(cq.stream, coords_buf.ptr, upload(ctx, rng).ptr, n, n, cb, codes_buf.ptr, None)
+    codes_buf, rng_buf = hip.Buffer(ctx, n * 4), upload(ctx, rng)
+    call.col_morton(cq.stream, coords_buf.ptr, rng_buf.ptr, n, n, cb, codes_buf.ptr, None)
     codes = download(cq, codes_buf, np.uint32)
     order = np.argsort(codes, kind="mergesort").astype(np.uint32)
     bounds_buf = hip.Buffer(ctx, (2 * n - 1) * 8 * cb)

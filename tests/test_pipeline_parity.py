@@ -34,7 +34,7 @@ def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=
     n = len(coords)
     collider = Collider(ctx, n, ngroups, group_size, dt)
     ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size,
-                         capacity=capacity if capacity is not None else 64 * n)
+                         capacity=capacity if capacity is not None else max(64 * n, min(n * (n - 1) // 2, 1 << 22)))
     cap = ref["count"] if capacity is None else capacity
     count, pairs = run_collider(ctx, cq, collider, coords, radii, cap)
     st = collider_state(cq, collider)
