@@ -231,9 +231,8 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 }
 
 size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
-    (void)n;
     return 256 /* scene range */ + col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4) +
-           col_radix_scratch_bytes(padded, 4, 4) + 256;
+           col_radix_scratch_bytes(padded, 4, 4) + col_lbvh_scratch_bytes(n, coord_bytes) + 512;
 }
 
 int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
@@ -245,18 +244,19 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
     hipStream_t s = col_stream(stream);
     COL_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), s));                 // collision.py:151-154
     if (n == 0) return COL_OK;
-    COL_HIP(hipMemsetAsync(flags, 0, (size_t)(2ull * n - 1) * sizeof(uint32_t), s));   // collision.py:147-150
+    (void)flags;   // the arrival counters of internalBounds (collision.py:147-150) are not needed: see lbvh.hip
     char *p = (char *)scratch;
     void *range = p;           p += 256;
     void *red_scratch = p;     p += col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4);
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    void *sort_scratch = p;
+    void *sort_scratch = p;    p += col_radix_scratch_bytes(padded, 4, 4);
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    void *lbvh_scratch = p;
     int rc;
     if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
     if ((rc = col_morton(stream, coords, range, n, padded, coord_bytes, codes0, ids0))) return rc;
     if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
-    if ((rc = col_bvh_build(stream, codes1, ids1, nodes, bounds, n, coord_bytes))) return rc;
-    if ((rc = col_bvh_refit(stream, bounds, flags, coords, radii, nodes, n, coord_bytes))) return rc;
+    if ((rc = col_lbvh(stream, codes1, ids1, coords, radii, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
     return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
 }
 

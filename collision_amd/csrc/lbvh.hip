@@ -1,0 +1,344 @@
+// Fused Karras build + AABB refit for the production path (col_collide).
+// Replaces fillInternal + generateBVH + leafBounds + internalBounds
+// (collision/collision.cl:55-162, enqueued at collision/collision.py:171-190) and produces the
+// same `nodes` and `bounds` arrays as bvh.hip's k_build + k_refit (which stay as the
+// reference-shaped, tree-generic kernels for the kernel-level parity tests).
+//
+// Why not walk the tree: internalBounds hands child boxes from one workgroup to another through
+// a flag atomic (collision.cl:152-161).  On MI355X that needs an agent-scope release + acquire
+// per level per wave (8 XCDs, non-coherent L2s) and cost 6.3 ms at 1 M spheres.  An LBVH node
+// covers a CONTIGUOUS range [first, last] of sorted leaves, so its box is a range-min/max query
+// over the leaf boxes, and min/max are exact and idempotent: any grouping gives the reference's
+// bits.  So there is no inter-workgroup hand-off at all:
+//
+//   k_chunk   one block per 256 consecutive sorted leaves: leaf boxes -> LDS sparse table
+//             (9 levels x 256 x 6 scalars), Karras topology for internal nodes [c*256, c*256+256),
+//             box of every node whose range stays inside the chunk = 2 table look-ups, written
+//             as one 32-byte record (box + traversal links) per thread.  A node that crosses the
+//             chunk boundary stores the half of its range that lies in this chunk (`partial`).
+//   k_group   (1-2 tiny launches) sparse tables over chunk totals, 256 chunks per group,
+//             then over group totals, ...
+//   k_cross   the ~1-2 % of nodes that cross chunks: partial[first] U partial[last] U
+//             O(1) table look-ups for the whole chunks in between.
+//
+// partial[] is indexed by NODE index: a crossing node that runs forward from `first` owns
+// partial[first]; the far end `last` of that node is the index of the backward crossing node
+// that ends at `last` (its nearest left-child ancestor-or-self chain: Karras gives a left child
+// the index of its last leaf), which stored the prefix box of its chunk up to `last` -- exactly
+// the piece the forward node is missing.  Symmetrically for backward nodes; leaf n-1 (no
+// internal node has that index) stores its prefix itself.
+#include "col_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr u32 END = 0xFFFFFFFFu;
+constexpr int C = 256;          // leaves per chunk == threads per block
+constexpr int LV = 9;           // table levels 0..8 (2^8 = 256)
+
+template <typename T> struct BT;
+template <> struct BT<float> { typedef float4 V4; typedef uint32_t Bits; };
+template <> struct BT<double> { typedef double4 V4; typedef uint64_t Bits; };
+
+template <typename T> struct Box { T lo[3], hi[3]; };
+
+template <typename T> __device__ __forceinline__ Box<T> box_empty() {
+    Box<T> b;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { b.lo[a] = (T)INFINITY; b.hi[a] = -(T)INFINITY; }
+    return b;
+}
+template <typename T> __device__ __forceinline__ void box_merge(Box<T> &a, const Box<T> &o) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = o.lo[k] < a.lo[k] ? o.lo[k] : a.lo[k];
+        a.hi[k] = o.hi[k] > a.hi[k] ? o.hi[k] : a.hi[k];
+    }
+}
+
+// global table / partial entry: two vec4 rows (lo.xyz, -) (hi.xyz, -)
+template <typename T> __device__ __forceinline__ void box_store(T *base, uint64_t entry, const Box<T> &b) {
+    typedef typename BT<T>::V4 V4;
+    V4 *p = reinterpret_cast<V4 *>(base) + 2 * entry;
+    V4 lo, hi;
+    lo.x = b.lo[0]; lo.y = b.lo[1]; lo.z = b.lo[2]; lo.w = (T)0;
+    hi.x = b.hi[0]; hi.y = b.hi[1]; hi.z = b.hi[2]; hi.w = (T)0;
+    p[0] = lo; p[1] = hi;
+}
+template <typename T> __device__ __forceinline__ Box<T> box_load(const T *base, uint64_t entry) {
+    typedef typename BT<T>::V4 V4;
+    const V4 *p = reinterpret_cast<const V4 *>(base) + 2 * entry;
+    const V4 lo = p[0], hi = p[1];
+    Box<T> b;
+    b.lo[0] = lo.x; b.lo[1] = lo.y; b.lo[2] = lo.z;
+    b.hi[0] = hi.x; b.hi[1] = hi.y; b.hi[2] = hi.z;
+    return b;
+}
+
+// LDS sparse table, structure of arrays: t[level][component][pos]
+template <typename T> struct Table { T v[LV][6][C]; };
+
+template <typename T> __device__ __forceinline__ void tab_put(Table<T> &t, int l, int pos, const Box<T> &b) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t.v[l][k][pos] = b.lo[k]; t.v[l][3 + k][pos] = b.hi[k]; }
+}
+template <typename T> __device__ __forceinline__ Box<T> tab_get(const Table<T> &t, int l, int pos) {
+    Box<T> b;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { b.lo[k] = t.v[l][k][pos]; b.hi[k] = t.v[l][3 + k][pos]; }
+    return b;
+}
+// level l from level l-1 (all 256 threads, barrier inside)
+template <typename T> __device__ __forceinline__ void tab_build(Table<T> &t, int tid) {
+    for (int l = 1; l < LV; l++) {
+        __syncthreads();
+        Box<T> b = tab_get(t, l - 1, tid);
+        const int o = tid + (1 << (l - 1));
+        if (o < C) box_merge(b, tab_get(t, l - 1, o));
+        tab_put(t, l, tid, b);
+    }
+    __syncthreads();
+}
+// union of entries [a, b], 0 <= a <= b < 256
+template <typename T> __device__ __forceinline__ Box<T> tab_query(const Table<T> &t, int a, int b) {
+    const int k = 31 - __clz(b - a + 1);
+    Box<T> r = tab_get(t, k, a);
+    box_merge(r, tab_get(t, k, b - (1 << k) + 1));
+    return r;
+}
+
+// same query against a global table laid out [group][level][256] of 2 x vec4 entries
+template <typename T> __device__ __forceinline__ Box<T> gtab_query(const T *tab, uint64_t group, int a, int b) {
+    const int k = 31 - __clz(b - a + 1);
+    const uint64_t base = (group * LV + k) * C;
+    Box<T> r = box_load(tab, base + a);
+    box_merge(r, box_load(tab, base + b - (1 << k) + 1));
+    return r;
+}
+
+// collision.cl:65-77
+__device__ __forceinline__ int delta(const u32 *__restrict__ codes, u32 n, u32 i, u32 ci, int64_t j) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    const u32 cj = codes[j];
+    return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
+}
+// the right child that starts at leaf k (see bvh.hip)
+__device__ __forceinline__ u32 right_child_at(const u32 *__restrict__ codes, u32 n, u32 k) {
+    if (k + 1 >= n) return (n - 1) + k;
+    const u32 ck = codes[k];
+    const bool fwd = delta(codes, n, k, ck, (int64_t)k + 1) > delta(codes, n, k, ck, (int64_t)k - 1);
+    return fwd ? k : (n - 1) + k;
+}
+
+template <typename T>
+__device__ __forceinline__ void record_store(T *bounds, uint64_t node, const Box<T> &b, u32 skip, u32 down) {
+    typedef typename BT<T>::V4 V4;
+    typedef typename BT<T>::Bits Bits;
+    V4 lo, hi;
+    lo.x = b.lo[0]; lo.y = b.lo[1]; lo.z = b.lo[2];
+    hi.x = b.hi[0]; hi.y = b.hi[1]; hi.z = b.hi[2];
+    const Bits s = (Bits)skip, d = (Bits)down;
+    lo.w = *reinterpret_cast<const T *>(&s);
+    hi.w = *reinterpret_cast<const T *>(&d);
+    V4 *p = reinterpret_cast<V4 *>(bounds) + 2 * node;
+    p[0] = lo; p[1] = hi;
+}
+template <typename T> __device__ __forceinline__ void links_store(T *bounds, uint64_t node, u32 skip, u32 down) {
+    typedef typename BT<T>::Bits Bits;
+    Bits *p = reinterpret_cast<Bits *>(bounds) + 8 * node;
+    p[3] = (Bits)skip;
+    p[7] = (Bits)down;
+}
+
+template <typename T>
+__global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ codes, const u32 *__restrict__ ids,
+                                             const T *__restrict__ coords, const T *__restrict__ radii,
+                                             col_node *__restrict__ nodes, T *__restrict__ bounds,
+                                             u32 *__restrict__ other_end, T *__restrict__ partial,
+                                             T *__restrict__ tab1, u32 n) {
+    typedef typename BT<T>::V4 V4;
+    __shared__ Table<T> tab;
+    const int tid = threadIdx.x;
+    const u32 chunk = blockIdx.x;
+    const u32 p = chunk * C + tid;
+    const u32 leaf_start = n - 1;
+    const bool valid = p < n;
+
+    // leaves: collision.cl:55-63 (fillInternal) + collision.cl:128-141 (leafBounds)
+    Box<T> leaf = box_empty<T>();
+    u32 id = 0;
+    if (valid) {
+        id = ids[p];
+        const V4 c = reinterpret_cast<const V4 *>(coords)[id];
+        const T r = radii[id];
+        leaf.lo[0] = c.x - r; leaf.lo[1] = c.y - r; leaf.lo[2] = c.z - r;
+        leaf.hi[0] = c.x + r; leaf.hi[1] = c.y + r; leaf.hi[2] = c.z + r;
+        nodes[leaf_start + p].right_edge = p;
+        nodes[leaf_start + p].data[0] = id;
+        record_store(bounds, (uint64_t)leaf_start + p, leaf, p + 1 < n ? right_child_at(codes, n, p + 1) : END, id);
+    }
+    tab_put(tab, 0, tid, leaf);
+    tab_build(tab, tid);
+
+    if (tid == 0) {   // chunk total -> level 0 of the first group table
+        const Box<T> all = tab_get(tab, LV - 1, 0);
+        box_store(tab1, ((uint64_t)(chunk / C) * LV + 0) * C + (chunk % C), all);
+    }
+    if (p == n - 1 && n > (u32)C) box_store(partial, p, tab_query(tab, 0, tid));   // prefix of the last leaf
+    if (p >= leaf_start) return;
+
+    // internal node p: collision.cl:81-121 (Karras 2012)
+    const u32 i = p, ci = codes[i];
+    const int dir = delta(codes, n, i, ci, (int64_t)i + 1) > delta(codes, n, i, ci, (int64_t)i - 1) ? 1 : -1;
+    const int delta_min = delta(codes, n, i, ci, (int64_t)i - dir);
+    int64_t len_max = 2;
+    while (delta(codes, n, i, ci, (int64_t)i + dir * len_max) > delta_min) len_max *= 2;
+    int64_t len = 0;
+    for (int64_t t = len_max / 2; t > 0; t /= 2)
+        if (delta(codes, n, i, ci, (int64_t)i + dir * (len + t)) > delta_min) len += t;
+    const u32 j = (u32)((int64_t)i + dir * len);
+    const int delta_node = delta(codes, n, i, ci, (int64_t)j);
+    int64_t s = 0, t = len;
+    do {
+        t = (t + 1) / 2;
+        if (delta(codes, n, i, ci, (int64_t)i + dir * (s + t)) > delta_node) s += t;
+    } while (t > 1);
+    const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
+    const u32 lo = min(i, j), hi = max(i, j);
+    const u32 child_a = (lo == gamma) ? leaf_start + gamma : gamma;
+    const u32 child_b = (hi == gamma + 1) ? leaf_start + gamma + 1 : gamma + 1;
+    nodes[i].right_edge = hi;
+    nodes[i].data[0] = child_a;
+    nodes[i].data[1] = child_b;
+    nodes[child_a].parent = i;
+    nodes[child_b].parent = i;
+    other_end[i] = j;
+
+    const u32 skip = hi + 1 < n ? right_child_at(codes, n, hi + 1) : END;
+    const u32 c0 = chunk * C;
+    if (lo >= c0 && hi < c0 + C) {
+        record_store(bounds, (uint64_t)i, tab_query(tab, (int)(lo - c0), (int)(hi - c0)), skip, child_a);
+    } else {
+        links_store(bounds, (uint64_t)i, skip, child_a);
+        // this chunk's half of the range: suffix from i (forward) or prefix up to i (backward)
+        box_store(partial, i, dir > 0 ? tab_query(tab, tid, C - 1) : tab_query(tab, 0, tid));
+    }
+}
+
+// Sparse table over `count` level-0 entries, 256 per group; group totals go to level 0 of `next`.
+template <typename T>
+__global__ __launch_bounds__(C) void k_group(T *__restrict__ tab, u32 count, T *__restrict__ next) {
+    __shared__ Table<T> t;
+    const int tid = threadIdx.x;
+    const u32 g = blockIdx.x;
+    const u32 e = g * C + tid;
+    const uint64_t base = (uint64_t)g * LV * C;
+    Box<T> b = e < count ? box_load(tab, base + tid) : box_empty<T>();
+    if (e >= count) box_store(tab, base + tid, b);
+    tab_put(t, 0, tid, b);
+    tab_build(t, tid);
+    for (int l = 1; l < LV; l++) box_store(tab, base + (uint64_t)l * C + tid, tab_get(t, l, tid));
+    if (tid == 0 && next) box_store(next, ((uint64_t)(g / C) * LV + 0) * C + (g % C), tab_get(t, LV - 1, 0));
+}
+
+struct Tabs { void *t[3]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
+                                               const T *__restrict__ partial, Tabs tabs, u32 n) {
+    typedef typename BT<T>::V4 V4;
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= n) return;
+    const u32 j = other_end[i];
+    const u32 first = min(i, j), last = max(i, j);
+    int64_t a = first / C, b = last / C;
+    if (a == b) return;
+    Box<T> box = box_load(partial, first);
+    box_merge(box, box_load(partial, last));
+    a += 1; b -= 1;                      // whole chunks strictly between the two ends
+    for (int h = 0; h < 3 && a <= b; h++) {
+        const T *tab = (const T *)tabs.t[h];
+        const int64_t ga = a / C, gb = b / C;
+        if (ga == gb) {
+            box_merge(box, gtab_query(tab, (uint64_t)ga, (int)(a % C), (int)(b % C)));
+            break;
+        }
+        box_merge(box, gtab_query(tab, (uint64_t)ga, (int)(a % C), C - 1));
+        box_merge(box, gtab_query(tab, (uint64_t)gb, 0, (int)(b % C)));
+        a = ga + 1; b = gb - 1;
+    }
+    // links (lane w) were written by k_chunk: store xyz only
+    T *row = bounds + 8ull * i;
+    row[0] = box.lo[0]; row[1] = box.lo[1]; row[2] = box.lo[2];
+    row[4] = box.hi[0]; row[5] = box.hi[1]; row[6] = box.hi[2];
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t other_end, partial, tab[3], total;
+    u32 count[3];    // level-0 entries of each table: chunks, groups, groups of groups
+};
+
+Layout layout(uint32_t n, int coord_bytes) {
+    Layout L;
+    const size_t entry = 8 * (size_t)coord_bytes;       // two vec4 rows
+    size_t off = 0;
+    L.other_end = off; off += align256((size_t)n * 4);
+    L.partial = off;   off += align256((size_t)n * entry);
+    u32 cnt = (u32)col_ceil_div(n, C);
+    for (int h = 0; h < 3; h++) {
+        L.count[h] = cnt;
+        const size_t groups = col_ceil_div(cnt, C);
+        L.tab[h] = off; off += align256(groups * LV * C * entry);
+        cnt = (u32)groups;
+    }
+    L.total = off;
+    return L;
+}
+
+template <typename T>
+int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, col_node *nodes,
+        T *bounds, char *scratch, u32 n) {
+    const Layout L = layout(n, sizeof(T));
+    u32 *other_end = (u32 *)(scratch + L.other_end);
+    T *partial = (T *)(scratch + L.partial);
+    Tabs tabs;
+    for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
+    const u32 nchunks = L.count[0];
+    k_chunk<T><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, nodes, bounds, other_end, partial,
+                                                  (T *)tabs.t[0], n);
+    COL_LAUNCH_OK();
+    if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
+    for (int h = 0; h < 3; h++) {
+        const u32 groups = (u32)col_ceil_div(L.count[h], C);
+        k_group<T><<<dim3(groups), dim3(C), 0, s>>>((T *)tabs.t[h], L.count[h], h + 1 < 3 ? (T *)tabs.t[h + 1] : nullptr);
+        COL_LAUNCH_OK();
+        if (groups < 2) break;
+    }
+    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, coord_bytes).total + 256; }
+
+int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
+             col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
+    if (n == 0) return COL_OK;
+    if (n >= 0x80000000u) return COL_EINVAL;
+    if (!scratch) return COL_ENOSCRATCH;
+    if (coord_bytes == 4)
+        return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, nodes,
+                          (float *)bounds, (char *)scratch, n);
+    if (coord_bytes == 8)
+        return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii, nodes,
+                           (double *)bounds, (char *)scratch, n);
+    return COL_EINVAL;
+}
+
+}  // extern "C"

@@ -62,6 +62,12 @@ def stage_times(hip_mod, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_
         call.col_fill(s, flags.ptr, zero.ctypes.data, 4, 2 * n - 1)
         call.col_bvh_refit(s, bounds.ptr, flags.ptr, coords_buf.ptr, radii_buf.ptr, nodes.ptr, n, cb)
 
+    lbvh_scratch = hip.Buffer(ctx, call.col_lbvh_scratch_bytes(n, cb))
+
+    def f_lbvh():
+        call.col_lbvh(s, codes1.ptr, ids1.ptr, coords_buf.ptr, radii_buf.ptr, nodes.ptr, bounds.ptr,
+                      lbvh_scratch.ptr, n, cb)
+
     def f_traverse():
         call.col_fill(s, n_buf.ptr, zero.ctypes.data, 4, 1)
         call.col_traverse(s, pairs_buf.ptr, n_buf.ptr, capacity, nodes.ptr, bounds.ptr, n, cb)
@@ -70,8 +76,9 @@ def stage_times(hip_mod, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_
         c.get_collisions(cq, coords_buf, radii_buf, n_buf, pairs_buf, capacity)
 
     out = {}
-    for name, fn in (("bounds", f_bounds), ("morton", f_morton), ("sort", f_sort), ("build", f_build),
-                     ("refit", f_refit), ("traverse", f_traverse)):
+    for name, fn in (("bounds", f_bounds), ("morton", f_morton), ("sort", f_sort),
+                     ("generic_build", f_build), ("generic_refit", f_refit), ("lbvh_build_refit", f_lbvh),
+                     ("traverse", f_traverse)):
         out[name] = round(_timed(cq, fn, reps), 4)
     # one radix pass, split
     f_hist(); f_scan()

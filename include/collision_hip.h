@@ -157,6 +157,15 @@ int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coord
 int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                  const col_node *nodes, const void *bounds, uint32_t n, int coord_bytes);
 
+/* Fused production form of the three calls above minus the traversal: Karras topology, leaf and
+ * internal AABBs and the traversal links in one pass, with no inter-workgroup hand-off (node
+ * boxes are range queries over the sorted leaf boxes; see csrc/lbvh.hip).  Same `nodes` and
+ * `bounds` contents as col_bvh_build(bounds != NULL) + col_bvh_refit. */
+size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes);
+int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords,
+             const void *radii, col_node *nodes, void *bounds, void *scratch, uint32_t n,
+             int coord_bytes);
+
 /* ---------------------------------------------------------------- whole path
  * Replaces Collider.get_collisions (collision/collision.py:130-198): the whole
  * enqueue DAG as one call.  codes/ids: two buffers of `padded` uint32 each

@@ -128,3 +128,42 @@ def test_random_trees_match_oracle(hip_env, oracle):
         np.testing.assert_equal(nodes["parent"][1:], ref["parent"][1:])
         np.testing.assert_equal(nodes["data"][:n - 1], ref["data"][:n - 1])
         np.testing.assert_equal(nodes["data"][n - 1:, 0], ref["data"][n - 1:, 0])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 1000, 65536, 65537, 70000, 300000])
+def test_fused_lbvh_equals_generic_kernels_and_oracle(hip_env, oracle, dt, n):
+    """col_lbvh (range-query refit, csrc/lbvh.hip) == col_bvh_build + col_bvh_refit == oracle,
+    on sorted codes with many duplicates; sizes straddle the 256-leaf chunk and 65536-leaf group."""
+    ctx, cq = hip_env
+    cb = np.dtype(dt).itemsize
+    rs = np.random.RandomState(n)
+    codes = np.sort(rs.randint(0, max(2, n // 3), size=n).astype(np.uint32))
+    ids = rs.permutation(n).astype(np.uint32)
+    coords = pad4(rs.uniform(-1, 1, size=(n, 3)).astype(dt))
+    radii = rs.uniform(0.001, 0.05, size=n).astype(dt)
+    codes_buf, ids_buf, coords_buf, radii_buf = (upload(ctx, a) for a in (codes, ids, coords, radii))
+    nn = 2 * n - 1
+
+    def fresh():
+        return upload(ctx, np.full(nn, NO_NODE, np.uint32).repeat(4)), upload(ctx, np.zeros((nn, 2, 4), dt))
+
+    nodes_a, bounds_a = fresh()
+    scratch = hip.Buffer(ctx, call.col_lbvh_scratch_bytes(n, cb))
+    call.col_lbvh(cq.stream, codes_buf.ptr, ids_buf.ptr, coords_buf.ptr, radii_buf.ptr, nodes_a.ptr, bounds_a.ptr,
+                  scratch.ptr, n, cb)
+    nodes_b, bounds_b = fresh()
+    flags = upload(ctx, np.zeros(nn, np.uint32))
+    call.col_bvh_build(cq.stream, codes_buf.ptr, ids_buf.ptr, nodes_b.ptr, bounds_b.ptr, n, cb)
+    call.col_bvh_refit(cq.stream, bounds_b.ptr, flags.ptr, coords_buf.ptr, radii_buf.ptr, nodes_b.ptr, n, cb)
+    na, nb = download(cq, nodes_a, Node, nn), download(cq, nodes_b, Node, nn)
+    ba, bb = download(cq, bounds_a, dt, (nn, 2, 4)), download(cq, bounds_b, dt, (nn, 2, 4))
+    np.testing.assert_array_equal(na, nb)                  # untouched fields keep the NO_NODE fill in both
+    np.testing.assert_array_equal(ba.view(np.uint8), bb.view(np.uint8))     # boxes AND lane-w links, bit for bit
+    if n >= 2:
+        ref_nodes = oracle.build_bvh(codes, ids)
+        ref_bounds = oracle.node_bounds(coords, radii, ref_nodes)
+        np.testing.assert_array_equal(na["right_edge"], ref_nodes["right_edge"])
+        np.testing.assert_array_equal(na["parent"][1:], ref_nodes["parent"][1:])
+        np.testing.assert_array_equal(na["data"][:n - 1], ref_nodes["data"][:n - 1])
+        np.testing.assert_array_equal(ba[:, :, :3], ref_bounds[:, :, :3])
