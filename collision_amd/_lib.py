@@ -64,6 +64,8 @@ _PROTOS = {
                              C.c_int]),
     "col_traverse": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                             C.c_int]),
+    "col_traverse_stats": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+                                  C.c_void_p, C.c_int]),
     "col_lbvh_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_int]),
     "col_lbvh": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_uint32, C.c_int]),

@@ -17,6 +17,7 @@
 // Karras numbering makes skip() local: the right child that starts at leaf k is internal
 // node k when node k's range runs forward, else leaf k (see right_child_at()).
 #include "col_common.h"
+#include <math.h>
 
 namespace {
 
@@ -153,39 +154,155 @@ __global__ __launch_bounds__(256) void k_refit(T *__restrict__ bounds, u32 *__re
 
 // traverse (collision.cl:174-226): pairs (id[q], id[p]) for every sorted leaf p > q whose box
 // strictly overlaps q's (collision.cl:164-166); the counter counts every hit, pairs beyond
-// `capacity` are dropped (collision.cl:203-207).  One hit append per wave-instruction:
-// ballot + mbcnt + a single atomic by the lowest hitting lane.
-template <typename T>
-__global__ __launch_bounds__(256) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
-                                                   const T *__restrict__ bounds, u32 n) {
+// `capacity` are dropped (collision.cl:203-207).
+//
+// Packet traversal, one wave = 64 consecutive sorted leaves (spatially compact, Morton order).
+// A lane-per-query walk spends its time in the texture addresser: every step is 64 different
+// cache lines per wave-instruction and a wave runs as long as its slowest lane (measured: 12
+// visits per query but 34 trips per wave, 4 us per trip).  Here the CANDIDATE is wave-uniform and
+// the 64 queries are tested against it in parallel:
+//   phase 1  candidates = the wave's own leaves 1..63, read from registers with v_readlane;
+//            lane q tests candidate p > q.
+//   phase 2  candidates beyond the wave: the skip-chain that starts after the wave's LAST leaf is
+//            the same for all 64 queries, so one uniform walk serves them all: one 32-byte
+//            record per step at a wave-uniform address, descend iff ANY lane's box overlaps.
+// Hits are appended with one atomic per candidate (ballot + mbcnt).
+template <typename T> __device__ __forceinline__ T readlane_t(T v, int l);
+template <> __device__ __forceinline__ float readlane_t(float v, int l) {
+    return __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+template <> __device__ __forceinline__ double readlane_t(double v, int l) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(b >> 32), l);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+// Pair output.  One global counter cannot take an atomic per hit: a single address retires
+// ~88 atomics/us on MI355X, and the first version of this kernel spent 0.3 ms of 0.39 ms there
+// for 32 k pairs.  Hits are staged in a wave-private LDS buffer; a wave flushes it with ONE
+// global atomic when it is full, and at the end of the (persistent) block the 16 waves' leftovers
+// are flushed together with one atomic for the whole block.
+constexpr int TW = 16;            // waves per block
+constexpr int TT = TW * 64;       // 1024 threads
+constexpr int CAPW = 256;         // staged pairs per wave (2 KB)
+
+struct PairSink {
+    uint2 *buf;        // this wave's LDS staging area
+    u32 count;         // wave-uniform number of staged pairs
+    u32 *pairs;
+    u32 *counter;
+    u32 capacity;
+    u32 lane;
+
+    __device__ __forceinline__ void copy_out(u32 base, u32 cnt) {
+        for (u32 i = lane; i < cnt; i += 64) {
+            const u32 k = base + i;
+            if (k < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * k) = buf[i];
+        }
+    }
+    __device__ __forceinline__ void flush() {          // wave-level, count > 0
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(counter, count);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        copy_out(base, count);
+        count = 0;
+    }
+    // `hits` is wave-uniform and non-zero; lanes set in it append (qid, pid)
+    __device__ __forceinline__ void emit(u64 hits, u32 qid, u32 pid) {
+        const u32 add = (u32)__popcll(hits);
+        if (count + add > (u32)CAPW) flush();
+        if ((hits >> lane) & 1ull) buf[count + mbcnt(hits)] = make_uint2(qid, pid);
+        count += add;
+    }
+};
+
+template <typename T, bool STATS>
+__global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
+                                                  const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
+                                                  int mode) {
     typedef typename BTypes<T>::V4 V4;
     typedef typename BTypes<T>::Bits Bits;
-    const u32 q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= n) return;
+    __shared__ uint2 s_buf[TW][CAPW];
+    __shared__ u32 s_cnt[TW];
+    __shared__ u32 s_base;
+    const u32 lane = lane_id(), w = threadIdx.x / 64;
     const u32 leaf_start = n - 1;
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
-    const V4 qmn = rows[2ull * (leaf_start + q)], qmx = rows[2ull * (leaf_start + q) + 1];
-    const u32 qid = (u32) * reinterpret_cast<const Bits *>(&qmx.w);
-    u32 idx = (u32) * reinterpret_cast<const Bits *>(&qmn.w);
-    const u32 lane = lane_id();
-    while (idx != END) {
-        const V4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
-        const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
-        const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
-        const bool overlap = qmx.x > a.x && qmn.x < b.x && qmx.y > a.y && qmn.y < b.y && qmx.z > a.z && qmn.z < b.z;
-        const bool leaf = idx >= leaf_start;
-        const bool hit = overlap && leaf;
-        const u64 hits = __ballot(hit);
-        if (hit) {
-            const int leader = (int)__builtin_ctzll(hits);
-            u32 base = 0;
-            if ((int)lane == leader) base = atomicAdd(counter, (u32)__popcll(hits));
-            base = __shfl(base, leader, COL_WAVE);
-            const u32 k = base + mbcnt(hits);
-            if (k < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * k) = make_uint2(qid, down);
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
+    const u32 npackets = (n + 63) / 64;
+    u32 trips = 0;
+
+    for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += gridDim.x * TW) {
+        const u32 q0 = packet * 64, q = q0 + lane;
+        const bool valid = q < n;
+        T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;   // empty box: never overlaps
+        u32 qid = 0, qskip = END;
+        if (valid) {
+            const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
+            lx = a.x; ly = a.y; lz = a.z; hx = b.x; hy = b.y; hz = b.z;
+            qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+            qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
         }
-        idx = (overlap && !leaf) ? down : skip;
+        const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
+
+        // phase 1: candidates inside the wave (x first: most candidates fail there for every lane)
+        for (int p = 1; p <= last && !(STATS && (mode & 1)); p++) {
+            const T plx = readlane_t(lx, p), phx = readlane_t(hx, p);
+            bool hit = (int)lane < p && hx > plx && lx < phx;
+            if (!__ballot(hit)) continue;
+            const T ply = readlane_t(ly, p), plz = readlane_t(lz, p);
+            const T phy = readlane_t(hy, p), phz = readlane_t(hz, p);
+            hit = hit && hy > ply && ly < phy && hz > plz && lz < phz;
+            const u64 hits = __ballot(hit);
+            if (hits) sink.emit(hits, qid, (u32)__builtin_amdgcn_readlane((int)qid, p));
+        }
+
+        // phase 2: everything after the wave's last leaf, one uniform walk
+        u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
+        if (STATS && (mode & 2)) idx = END;
+        while (idx != END) {
+            if (STATS) trips++;
+            const V4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
+            const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+            const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
+            const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
+            const u64 hits = __ballot(overlap);
+            u32 next = skip;
+            if (hits) {
+                if (idx >= leaf_start) sink.emit(hits, qid, down);
+                else next = down;
+            }
+            idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
+        }
     }
+
+    // block-level flush of what is still staged: one atomic for the 16 waves
+    if (lane == 0) s_cnt[w] = sink.count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (int i = 0; i < TW; i++) { const u32 c = s_cnt[i]; s_cnt[i] = total; total += c; }
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    sink.copy_out(s_base + s_cnt[w], sink.count);
+    if (STATS && threadIdx.x == 0) {   // diagnostics (one atomic per block)
+        atomicAdd(&stats[2], 1ull);
+    }
+    if (STATS && lane == 0) atomicAdd(&stats[0], (u64)trips);
+}
+
+template <typename T, bool STATS>
+int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
+                    uint32_t n, uint64_t *stats, int mode) {
+    const u32 npackets = (n + 63) / 64;
+    u32 blocks = (u32)col_ceil_div(npackets, TW);
+    if (blocks > 512) blocks = 512;               // 2 resident blocks of 16 waves per CU, grid-stride beyond
+    k_traverse<T, STATS><<<dim3(blocks), dim3(TT), 0, col_stream(stream)>>>(pairs, counter, capacity, (const T *)bounds, n,
+                                                                          (u64 *)stats, mode);
+    COL_LAUNCH_OK();
+    return COL_OK;
 }
 
 }  // namespace
@@ -222,12 +339,19 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     (void)nodes;   // the traversal runs on the 32-byte records in `bounds` alone
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
-    if (coord_bytes == 4) k_traverse<float><<<grid, block, 0, col_stream(stream)>>>(pairs, counter, capacity, (const float *)bounds, n);
-    else if (coord_bytes == 8) k_traverse<double><<<grid, block, 0, col_stream(stream)>>>(pairs, counter, capacity, (const double *)bounds, n);
-    else return COL_EINVAL;
-    COL_LAUNCH_OK();
-    return COL_OK;
+    if (coord_bytes == 4) return launch_traverse<float, false>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
+    if (coord_bytes == 8) return launch_traverse<double, false>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
+    return COL_EINVAL;
+}
+
+// Diagnostics: same traversal, also accumulates stats[0] = phase-2 steps summed over waves,
+// stats[2] = blocks.  mode bit0 skips phase 1, bit1 skips phase 2 (timing ablations only).
+int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
+                       uint32_t n, int coord_bytes, uint64_t *stats, int mode) {
+    if (n < 2) return COL_OK;
+    if (coord_bytes == 4) return launch_traverse<float, true>(stream, pairs, counter, capacity, bounds, n, stats, mode);
+    if (coord_bytes == 8) return launch_traverse<double, true>(stream, pairs, counter, capacity, bounds, n, stats, mode);
+    return COL_EINVAL;
 }
 
 size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {

@@ -157,6 +157,11 @@ int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coord
 int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                  const col_node *nodes, const void *bounds, uint32_t n, int coord_bytes);
 
+/* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
+ * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
+int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
+                       const void *bounds, uint32_t n, int coord_bytes, uint64_t *stats, int mode);
+
 /* Fused production form of the three calls above minus the traversal: Karras topology, leaf and
  * internal AABBs and the traversal links in one pass, with no inter-workgroup hand-off (node
  * boxes are range queries over the sorted leaf boxes; see csrc/lbvh.hip).  Same `nodes` and

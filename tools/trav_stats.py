@@ -1,0 +1,23 @@
+import sys, numpy as np
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+from collision_amd import hip
+from collision_amd._lib import call
+from collision_amd.collision import Collider
+import bench
+ctx=hip.Context(); cq=hip.CommandQueue(ctx)
+for n in (1000000,):
+    coords,radii=bench.uniform_scene(n)
+    cb,rb=hip.Buffer(ctx,hostbuf=coords),hip.Buffer(ctx,hostbuf=radii)
+    nb,pb=hip.Buffer(ctx,4),hip.Buffer(ctx,(1<<17)*8)
+    col=Collider(ctx,n,64,256)
+    col.get_collisions(cq,cb,rb,nb,pb,1<<17); cq.finish()
+    for mode in (0,1,2,3):
+        stats=hip.Buffer(ctx,hostbuf=np.zeros(3,np.uint64))
+        z=np.zeros(1,np.uint32)
+        def run():
+            call.col_fill(cq.stream, nb.ptr, z.ctypes.data, 4, 1)
+            call.col_traverse_stats(cq.stream,pb.ptr,nb.ptr,1<<17,col._bounds_buf.ptr,n,4,stats.ptr,mode)
+        run(); cq.finish()
+        ms=bench.time_events(hip,cq,run,10)
+        s=hip.read_buffer(cq,stats,np.uint64,3)
+        print('mode',mode,'ms',round(ms,4),'phase2 steps/packet',s[0]/11.0/((n+63)//64),'pairs', hip.read_buffer(cq,nb,np.uint32,1))
