@@ -116,18 +116,33 @@ template <typename T> __device__ __forceinline__ Box<T> gtab_query(const T *tab,
     return r;
 }
 
+// Sorted codes seen through an LDS window [w0, w0 + WIN) around the chunk: almost every Karras
+// probe of a node stays within a few hundred leaves of it, so the dependent-load chains of the
+// search run at LDS latency; probes outside the window fall back to global memory.
+constexpr int HALO = 256;
+constexpr int WIN = C + 2 * HALO;
+struct Codes {
+    const u32 *__restrict__ g;
+    const u32 *win;
+    int64_t w0;
+    u32 n;
+    __device__ __forceinline__ u32 at(int64_t j) const {
+        const int64_t o = j - w0;
+        return (o >= 0 && o < WIN) ? win[o] : g[j];
+    }
+};
 // collision.cl:65-77
-__device__ __forceinline__ int delta(const u32 *__restrict__ codes, u32 n, u32 i, u32 ci, int64_t j) {
-    if (j < 0 || j >= (int64_t)n) return -1;
-    const u32 cj = codes[j];
+__device__ __forceinline__ int delta(const Codes &c, u32 i, u32 ci, int64_t j) {
+    if (j < 0 || j >= (int64_t)c.n) return -1;
+    const u32 cj = c.at(j);
     return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
 }
 // the right child that starts at leaf k (see bvh.hip)
-__device__ __forceinline__ u32 right_child_at(const u32 *__restrict__ codes, u32 n, u32 k) {
-    if (k + 1 >= n) return (n - 1) + k;
-    const u32 ck = codes[k];
-    const bool fwd = delta(codes, n, k, ck, (int64_t)k + 1) > delta(codes, n, k, ck, (int64_t)k - 1);
-    return fwd ? k : (n - 1) + k;
+__device__ __forceinline__ u32 right_child_at(const Codes &c, u32 k) {
+    if (k + 1 >= c.n) return (c.n - 1) + k;
+    const u32 ck = c.at(k);
+    const bool fwd = delta(c, k, ck, (int64_t)k + 1) > delta(c, k, ck, (int64_t)k - 1);
+    return fwd ? k : (c.n - 1) + k;
 }
 
 template <typename T>
@@ -150,17 +165,59 @@ template <typename T> __device__ __forceinline__ void links_store(T *bounds, uin
     p[7] = (Bits)down;
 }
 
+// LDS image of one chunk: leaf boxes, finished boxes of in-chunk internal nodes, ready flags.
+template <typename T> struct ChunkLds {
+    T leaf[6][C];
+    T node[6][C];
+    u32 ready[C];
+    T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
+};
+template <typename T> __device__ __forceinline__ Box<T> soa_get(const T (&a)[6][C], int pos) {
+    Box<T> b;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { b.lo[k] = a[k][pos]; b.hi[k] = a[3 + k][pos]; }
+    return b;
+}
+template <typename T> __device__ __forceinline__ void soa_put(T (&a)[6][C], int pos, const Box<T> &b) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a[k][pos] = b.lo[k]; a[3 + k][pos] = b.hi[k]; }
+}
+template <typename T> __device__ __forceinline__ Box<T> box_shfl_up(const Box<T> &b, int o) {
+    Box<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r.lo[k] = __shfl_up(b.lo[k], o, COL_WAVE); r.hi[k] = __shfl_up(b.hi[k], o, COL_WAVE); }
+    return r;
+}
+template <typename T> __device__ __forceinline__ Box<T> box_shfl_down(const Box<T> &b, int o) {
+    Box<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r.lo[k] = __shfl_down(b.lo[k], o, COL_WAVE); r.hi[k] = __shfl_down(b.hi[k], o, COL_WAVE); }
+    return r;
+}
+
+// node records without the `parent` word, which the parent's thread writes (collision.cl:119-120)
+struct __attribute__((packed, aligned(4))) LeafTail { u32 right_edge, id; };
+struct __attribute__((packed, aligned(4))) InnerTail { u32 right_edge, child_a, child_b; };
+
 template <typename T>
-__global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ codes, const u32 *__restrict__ ids,
+__global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial,
-                                             T *__restrict__ tab1, u32 n) {
+                                             T *__restrict__ tab1, u32 n, int dbg) {
     typedef typename BT<T>::V4 V4;
-    __shared__ Table<T> tab;
-    const int tid = threadIdx.x;
+    __shared__ ChunkLds<T> lds;
+    __shared__ u32 s_codes[WIN];
+    const int tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
     const u32 chunk = blockIdx.x;
-    const u32 p = chunk * C + tid;
+    const u32 c0 = chunk * C;
+    const u32 p = c0 + tid;
+    Codes codes = {gcodes, s_codes, (int64_t)c0 - HALO, n};
+    for (int o = tid; o < WIN; o += C) {
+        const int64_t j = codes.w0 + o;
+        s_codes[o] = (j >= 0 && j < (int64_t)n) ? gcodes[j] : 0u;
+    }
+    lds.ready[tid] = 0;
     const u32 leaf_start = n - 1;
     const bool valid = p < n;
 
@@ -169,59 +226,92 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ codes, cons
     u32 id = 0;
     if (valid) {
         id = ids[p];
-        const V4 c = reinterpret_cast<const V4 *>(coords)[id];
-        const T r = radii[id];
+        const u32 gid = (dbg & 1) ? p : id;
+        const V4 c = reinterpret_cast<const V4 *>(coords)[gid];
+        const T r = radii[gid];
         leaf.lo[0] = c.x - r; leaf.lo[1] = c.y - r; leaf.lo[2] = c.z - r;
         leaf.hi[0] = c.x + r; leaf.hi[1] = c.y + r; leaf.hi[2] = c.z + r;
-        nodes[leaf_start + p].right_edge = p;
-        nodes[leaf_start + p].data[0] = id;
-        record_store(bounds, (uint64_t)leaf_start + p, leaf, p + 1 < n ? right_child_at(codes, n, p + 1) : END, id);
     }
-    tab_put(tab, 0, tid, leaf);
-    tab_build(tab, tid);
+    soa_put(lds.leaf, tid, leaf);
 
-    if (tid == 0) {   // chunk total -> level 0 of the first group table
-        const Box<T> all = tab_get(tab, LV - 1, 0);
-        box_store(tab1, ((uint64_t)(chunk / C) * LV + 0) * C + (chunk % C), all);
+    // inclusive prefix / suffix unions over the chunk (wave shuffles, then the 4 wave totals)
+    Box<T> pre = leaf, suf = leaf;
+#pragma unroll
+    for (int o = 1; o < COL_WAVE; o <<= 1) {
+        const Box<T> up = box_shfl_up(pre, o), dn = box_shfl_down(suf, o);
+        if (lane >= o) box_merge(pre, up);
+        if (lane + o < COL_WAVE) box_merge(suf, dn);
     }
-    if (p == n - 1 && n > (u32)C) box_store(partial, p, tab_query(tab, 0, tid));   // prefix of the last leaf
-    if (p >= leaf_start) return;
+    if (lane == COL_WAVE - 1) { for (int k = 0; k < 3; k++) { lds.wave_tot[0][w][k] = pre.lo[k]; lds.wave_tot[0][w][3 + k] = pre.hi[k]; } }
+    if (lane == 0) { for (int k = 0; k < 3; k++) { lds.wave_tot[1][w][k] = suf.lo[k]; lds.wave_tot[1][w][3 + k] = suf.hi[k]; } }
+    __syncthreads();       // codes window, leaf boxes, ready flags and wave totals are in LDS
+    for (int ww = 0; ww < C / COL_WAVE; ww++) {
+        Box<T> t;
+        for (int k = 0; k < 3; k++) { t.lo[k] = lds.wave_tot[ww < w ? 0 : 1][ww][k]; t.hi[k] = lds.wave_tot[ww < w ? 0 : 1][ww][3 + k]; }
+        if (ww < w) box_merge(pre, t);
+        if (ww > w) box_merge(suf, t);
+    }
+
+    if (valid) {
+        LeafTail tail = {p, id};
+        *reinterpret_cast<LeafTail *>(&nodes[leaf_start + p].right_edge) = tail;
+        record_store(bounds, (uint64_t)leaf_start + p, leaf, p + 1 < n ? right_child_at(codes, p + 1) : END, id);
+    }
+    if (tid == 0)          // chunk total -> level 0 of the first group table
+        box_store(tab1, ((uint64_t)(chunk / C) * LV + 0) * C + (chunk % C), suf);
+    if (p == n - 1 && n > (u32)C) box_store(partial, p, pre);      // prefix of the last leaf
+    if (p >= leaf_start || (dbg & 4)) return;                      // no barrier below this line
 
     // internal node p: collision.cl:81-121 (Karras 2012)
-    const u32 i = p, ci = codes[i];
-    const int dir = delta(codes, n, i, ci, (int64_t)i + 1) > delta(codes, n, i, ci, (int64_t)i - 1) ? 1 : -1;
-    const int delta_min = delta(codes, n, i, ci, (int64_t)i - dir);
+    const u32 i = p, ci = codes.at(i);
+    const int dir = delta(codes, i, ci, (int64_t)i + 1) > delta(codes, i, ci, (int64_t)i - 1) ? 1 : -1;
+    const int delta_min = delta(codes, i, ci, (int64_t)i - dir);
     int64_t len_max = 2;
-    while (delta(codes, n, i, ci, (int64_t)i + dir * len_max) > delta_min) len_max *= 2;
+    while (delta(codes, i, ci, (int64_t)i + dir * len_max) > delta_min) len_max *= 2;
     int64_t len = 0;
     for (int64_t t = len_max / 2; t > 0; t /= 2)
-        if (delta(codes, n, i, ci, (int64_t)i + dir * (len + t)) > delta_min) len += t;
+        if (delta(codes, i, ci, (int64_t)i + dir * (len + t)) > delta_min) len += t;
     const u32 j = (u32)((int64_t)i + dir * len);
-    const int delta_node = delta(codes, n, i, ci, (int64_t)j);
+    const int delta_node = delta(codes, i, ci, (int64_t)j);
     int64_t s = 0, t = len;
     do {
         t = (t + 1) / 2;
-        if (delta(codes, n, i, ci, (int64_t)i + dir * (s + t)) > delta_node) s += t;
+        if (delta(codes, i, ci, (int64_t)i + dir * (s + t)) > delta_node) s += t;
     } while (t > 1);
     const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
     const u32 lo = min(i, j), hi = max(i, j);
-    const u32 child_a = (lo == gamma) ? leaf_start + gamma : gamma;
-    const u32 child_b = (hi == gamma + 1) ? leaf_start + gamma + 1 : gamma + 1;
-    nodes[i].right_edge = hi;
-    nodes[i].data[0] = child_a;
-    nodes[i].data[1] = child_b;
-    nodes[child_a].parent = i;
-    nodes[child_b].parent = i;
+    const bool a_leaf = lo == gamma, b_leaf = hi == gamma + 1;
+    const u32 child_a = a_leaf ? leaf_start + gamma : gamma;
+    const u32 child_b = b_leaf ? leaf_start + gamma + 1 : gamma + 1;
+    InnerTail tail = {hi, child_a, child_b};
+    *reinterpret_cast<InnerTail *>(&nodes[i].right_edge) = tail;
+    if (!(dbg & 2)) { nodes[child_a].parent = i; nodes[child_b].parent = i; }
     other_end[i] = j;
 
-    const u32 skip = hi + 1 < n ? right_child_at(codes, n, hi + 1) : END;
-    const u32 c0 = chunk * C;
+    const u32 skip = hi + 1 < n ? right_child_at(codes, hi + 1) : END;
+    if (dbg & 8) return;
     if (lo >= c0 && hi < c0 + C) {
-        record_store(bounds, (uint64_t)i, tab_query(tab, (int)(lo - c0), (int)(hi - c0)), skip, child_a);
+        // Both children live in this chunk.  Wait (in LDS, workgroup scope) until their boxes are
+        // final, merge, publish.  The tree is at most 64 levels deep, so this ends after <= 64
+        // rounds; finished lanes idle at the loop exit while the others retry.
+        const int la = (int)(gamma - c0), lb = la + 1;
+        Box<T> box;
+        for (bool done = false; !done;) {
+            const bool ra = a_leaf || __hip_atomic_load(&lds.ready[la], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool rb = b_leaf || __hip_atomic_load(&lds.ready[lb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ra && rb) {
+                box = a_leaf ? soa_get(lds.leaf, la) : soa_get(lds.node, la);
+                box_merge(box, b_leaf ? soa_get(lds.leaf, lb) : soa_get(lds.node, lb));
+                soa_put(lds.node, tid, box);
+                __hip_atomic_store(&lds.ready[tid], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                done = true;
+            }
+        }
+        record_store(bounds, (uint64_t)i, box, skip, child_a);
     } else {
         links_store(bounds, (uint64_t)i, skip, child_a);
         // this chunk's half of the range: suffix from i (forward) or prefix up to i (backward)
-        box_store(partial, i, dir > 0 ? tab_query(tab, tid, C - 1) : tab_query(tab, 0, tid));
+        box_store(partial, i, dir > 0 ? suf : pre);
     }
 }
 
@@ -273,6 +363,7 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
     row[4] = box.hi[0]; row[5] = box.hi[1]; row[6] = box.hi[2];
 }
 
+int g_dbg = 0;
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
@@ -307,7 +398,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
     k_chunk<T><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, nodes, bounds, other_end, partial,
-                                                  (T *)tabs.t[0], n);
+                                                  (T *)tabs.t[0], n, g_dbg);
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
     for (int h = 0; h < 3; h++) {
@@ -324,6 +415,8 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
 }  // namespace
 
 extern "C" {
+
+void col_debug_lbvh(int mode) { g_dbg = mode; }
 
 size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, coord_bytes).total + 256; }
 
