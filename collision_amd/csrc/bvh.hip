@@ -215,9 +215,13 @@ struct PairSink {
         if ((hits >> lane) & 1ull) buf[count + mbcnt(hits)] = make_uint2(qid, pid);
         count += add;
     }
+    // same, but every hitting lane brings its own partner id
+    __device__ __forceinline__ void emit_each(u64 hits, u32 qid, u32 pid) { emit(hits, qid, pid); }
 };
 
-template <typename T, bool STATS>
+// K packets per wave are walked together in phase 2 so that K dependent record loads are in
+// flight per wave instead of one (the walk is latency bound: one 32-byte record per step).
+template <typename T, int K, bool VEC>
 __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode) {
@@ -231,49 +235,71 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
     const u32 npackets = (n + 63) / 64;
-    u32 trips = 0;
+    const u32 nwaves = gridDim.x * TW;
+    u64 trips = 0;
 
-    for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += gridDim.x * TW) {
-        const u32 q0 = packet * 64, q = q0 + lane;
-        const bool valid = q < n;
-        T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;   // empty box: never overlaps
-        u32 qid = 0, qskip = END;
-        if (valid) {
-            const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
-            lx = a.x; ly = a.y; lz = a.z; hx = b.x; hy = b.y; hz = b.z;
-            qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
-            qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
-        }
-        const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
-
-        // phase 1: candidates inside the wave (x first: most candidates fail there for every lane)
-        for (int p = 1; p <= last && !(STATS && (mode & 1)); p++) {
-            const T plx = readlane_t(lx, p), phx = readlane_t(hx, p);
-            bool hit = (int)lane < p && hx > plx && lx < phx;
-            if (!__ballot(hit)) continue;
-            const T ply = readlane_t(ly, p), plz = readlane_t(lz, p);
-            const T phy = readlane_t(hy, p), phz = readlane_t(hz, p);
-            hit = hit && hy > ply && ly < phy && hz > plz && lz < phz;
-            const u64 hits = __ballot(hit);
-            if (hits) sink.emit(hits, qid, (u32)__builtin_amdgcn_readlane((int)qid, p));
-        }
-
-        // phase 2: everything after the wave's last leaf, one uniform walk
-        u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
-        if (STATS && (mode & 2)) idx = END;
-        while (idx != END) {
-            if (STATS) trips++;
-            const V4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
-            const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
-            const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
-            const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
-            const u64 hits = __ballot(overlap);
-            u32 next = skip;
-            if (hits) {
-                if (idx >= leaf_start) sink.emit(hits, qid, down);
-                else next = down;
+    for (u32 base = (blockIdx.x * TW + w) * K; base < npackets; base += nwaves * K) {
+        T lx[K], ly[K], lz[K], hx[K], hy[K], hz[K];
+        u32 qid[K], idx[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const u32 packet = base + k;
+            const u32 q0 = packet * 64, q = q0 + lane;
+            lx[k] = (T)INFINITY; ly[k] = lx[k]; lz[k] = lx[k]; hx[k] = -lx[k]; hy[k] = -lx[k]; hz[k] = -lx[k];   // empty
+            qid[k] = 0; idx[k] = END;
+            u32 qskip = END;
+            if (packet < npackets && q < n) {
+                const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
+                lx[k] = a.x; ly[k] = a.y; lz[k] = a.z; hx[k] = b.x; hy[k] = b.y; hz[k] = b.z;
+                qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+                qid[k] = (u32) * reinterpret_cast<const Bits *>(&b.w);
             }
-            idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
+            if (packet >= npackets) continue;
+            const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
+            // phase 1: candidates inside the packet (x first: cheap reject for the whole wave)
+            for (int p = 1; p <= last && !(mode & 1); p++) {
+                const T plx = readlane_t(lx[k], p), phx = readlane_t(hx[k], p);
+                bool hit = (int)lane < p && hx[k] > plx && lx[k] < phx;
+                if (!__ballot(hit)) continue;
+                const T ply = readlane_t(ly[k], p), plz = readlane_t(lz[k], p);
+                const T phy = readlane_t(hy[k], p), phz = readlane_t(hz[k], p);
+                hit = hit && hy[k] > ply && ly[k] < phy && hz[k] > plz && lz[k] < phz;
+                const u64 hits = __ballot(hit);
+                if (hits) sink.emit(hits, qid[k], (u32)__builtin_amdgcn_readlane((int)qid[k], p));
+            }
+            idx[k] = (u32)__builtin_amdgcn_readlane((int)qskip, last);
+            if (mode & 2) idx[k] = END;
+        }
+
+        // phase 2: everything after each packet's last leaf; K uniform walks in lock step
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) any |= idx[k] != END;
+            if (!any) break;
+            V4 a[K], b[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {                      // issue all K record loads first
+                u32 li = idx[k] != END ? idx[k] : 0u;           // finished walks re-read the root (harmless)
+                if (VEC) asm volatile("" : "+v"(li));           // vector load at a uniform address
+                a[k] = rows[2ull * li]; b[k] = rows[2ull * li + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (idx[k] == END) continue;
+                trips++;
+                const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a[k].w);
+                const u32 down = (u32) * reinterpret_cast<const Bits *>(&b[k].w);
+                const bool overlap = hx[k] > a[k].x && lx[k] < b[k].x && hy[k] > a[k].y && ly[k] < b[k].y &&
+                                     hz[k] > a[k].z && lz[k] < b[k].z;
+                const u64 hits = __ballot(overlap);
+                u32 next = skip;
+                if (hits) {
+                    if (idx[k] >= leaf_start) sink.emit(hits, qid[k], down);
+                    else next = down;
+                }
+                idx[k] = (u32)__builtin_amdgcn_readfirstlane((int)next);
+            }
         }
     }
 
@@ -287,20 +313,88 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     }
     __syncthreads();
     sink.copy_out(s_base + s_cnt[w], sink.count);
-    if (STATS && threadIdx.x == 0) {   // diagnostics (one atomic per block)
-        atomicAdd(&stats[2], 1ull);
+    if (stats) {                       // diagnostics: phase-2 steps, one atomic per block
+        __shared__ unsigned long long s_trips;
+        if (threadIdx.x == 0) s_trips = 0;
+        __syncthreads();
+        if (lane == 0) atomicAdd(&s_trips, (unsigned long long)trips);
+        __syncthreads();
+        if (threadIdx.x == 0) { atomicAdd(&stats[0], (u64)s_trips); atomicAdd(&stats[2], 1ull); }
     }
-    if (STATS && lane == 0) atomicAdd(&stats[0], (u64)trips);
 }
 
-template <typename T, bool STATS>
+// Lane-per-query variant: every lane walks its own skip chain (12 visits per query on the uniform
+// scene).  Divergent, but it has no intra-wave phase; kept for sparse scenes, selected by
+// col_traverse's `variant` heuristics and for A/B measurements.
+template <typename T>
+__global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
+                                                       const T *__restrict__ bounds, u32 n, int g_skip) {
+    typedef typename BTypes<T>::V4 V4;
+    typedef typename BTypes<T>::Bits Bits;
+    __shared__ uint2 s_buf[TW][CAPW];
+    __shared__ u32 s_cnt[TW];
+    __shared__ u32 s_base;
+    const u32 lane = lane_id(), w = threadIdx.x / 64;
+    const u32 leaf_start = n - 1;
+    const V4 *rows = reinterpret_cast<const V4 *>(bounds);
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
+    const u32 npackets = (n + 63) / 64;
+    for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += gridDim.x * TW) {
+        const u32 q = packet * 64 + lane;
+        T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;
+        u32 qid = 0, idx = END;
+        if (q < n) {
+            const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
+            lx = a.x; ly = a.y; lz = a.z; hx = b.x; hy = b.y; hz = b.z;
+            idx = (u32) * reinterpret_cast<const Bits *>(&a.w);
+            qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
+        }
+        if (g_skip) idx = END;
+        while (__ballot(idx != END)) {              // wave-uniform loop so that emit() stays convergent
+            bool hit = false;
+            u32 down = 0;
+            if (idx != END) {
+                const V4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
+                const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+                down = (u32) * reinterpret_cast<const Bits *>(&b.w);
+                const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
+                const bool leaf = idx >= leaf_start;
+                hit = overlap && leaf;
+                idx = (overlap && !leaf) ? down : skip;
+            }
+            const u64 hits = __ballot(hit);
+            if (hits) sink.emit_each(hits, qid, down);
+        }
+    }
+    if (lane == 0) s_cnt[w] = sink.count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (int i = 0; i < TW; i++) { const u32 c = s_cnt[i]; s_cnt[i] = total; total += c; }
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    sink.copy_out(s_base + s_cnt[w], sink.count);
+}
+
+int g_traverse_variant = 0;       // diagnostics switch, see col_debug_traverse
+
+template <typename T>
 int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                     uint32_t n, uint64_t *stats, int mode) {
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;               // 2 resident blocks of 16 waves per CU, grid-stride beyond
-    k_traverse<T, STATS><<<dim3(blocks), dim3(TT), 0, col_stream(stream)>>>(pairs, counter, capacity, (const T *)bounds, n,
-                                                                          (u64 *)stats, mode);
+    dim3 g(blocks), t(TT);
+    hipStream_t s = col_stream(stream);
+    const T *bd = (const T *)bounds;
+    u64 *st = (u64 *)stats;
+    // Measured on MI355X, 1 M spheres (tools/trav_ab.py): packet 0.109 ms vs lane-per-query 0.120 ms on
+    // the uniform scene, 0.78 vs 1.04 ms on a clustered one (11 M pairs).  Walking K = 2 / 4 packets per
+    // wave in lock step is slower (0.134 / 0.169 ms): the packet walk is bound by instruction issue, not by
+    // the latency of its dependent loads, so only K = 1 is instantiated.
+    if (g_traverse_variant == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
+    else k_traverse<T, 1, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -308,6 +402,8 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
 }  // namespace
 
 extern "C" {
+
+void col_debug_traverse(int variant) { g_traverse_variant = variant; }
 
 int col_bvh_build(void *stream, const uint32_t *codes, const uint32_t *ids, col_node *nodes, void *bounds,
                   uint32_t n, int coord_bytes) {
@@ -339,8 +435,8 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     (void)nodes;   // the traversal runs on the 32-byte records in `bounds` alone
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    if (coord_bytes == 4) return launch_traverse<float, false>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
-    if (coord_bytes == 8) return launch_traverse<double, false>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
+    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
+    if (coord_bytes == 8) return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0);
     return COL_EINVAL;
 }
 
@@ -349,8 +445,8 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                        uint32_t n, int coord_bytes, uint64_t *stats, int mode) {
     if (n < 2) return COL_OK;
-    if (coord_bytes == 4) return launch_traverse<float, true>(stream, pairs, counter, capacity, bounds, n, stats, mode);
-    if (coord_bytes == 8) return launch_traverse<double, true>(stream, pairs, counter, capacity, bounds, n, stats, mode);
+    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, stats, mode);
+    if (coord_bytes == 8) return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, stats, mode);
     return COL_EINVAL;
 }
 
