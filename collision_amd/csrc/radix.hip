@@ -89,7 +89,7 @@ template <typename K, int VB>
 __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
-                                                const u32 *__restrict__ offsets) {
+                                                const u32 *__restrict__ offsets, int dbg) {
     constexpr bool HAS_V = VB > 0;
     constexpr bool V_LDS = VB == 4 || VB == 8;       // small values are staged through LDS
     typedef typename Val<(VB > 0 ? VB : 4)>::T V;
@@ -102,7 +102,15 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
     const V *vals_in = reinterpret_cast<const V *>(vals_in_);
     V *vals_out = reinterpret_cast<V *>(vals_out_);
     const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
-    const u32 b = blockIdx.x;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an
+    // XCD), each with its own L2.  Consecutive tiles write ADJACENT runs of every digit, so give each
+    // XCD a contiguous range of tiles: the ~64-byte runs of neighbouring tiles then meet in one L2 and
+    // leave it as full lines instead of partial-line writes from 8 different L2s.  (Speed only.)
+    u32 b = blockIdx.x;
+    if (!(dbg & 4)) {
+        const u32 q = nblocks / 8, r = nblocks % 8, xcd = b % 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
     const uint64_t tile_base = (uint64_t)b * TILE;
     const u32 valid = (u32)min((uint64_t)TILE, n - tile_base);
 
@@ -178,7 +186,8 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
         const u32 i = k * RT + tid;
         if (i < valid) {
             const K kk = s_keys[i];
-            const u32 g = s_goff[digit_of(kk, shift)] + i;
+            u32 g = s_goff[digit_of(kk, shift)] + i;
+            if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
             keys_out[g] = kk;
             if (V_LDS) vals_out[g] = s_vals[i];
         }
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
     }
 }
 
+int g_radix_dbg = 0;
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, TILE); }
 
@@ -296,11 +306,11 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
     const int shift = pass * 8;
     if (!vals || !vals_out) vb = 0;
     switch (vb) {
-    case 0: k_scatter<K, 0><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets); break;
-    case 4: k_scatter<K, 4><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
-    case 8: k_scatter<K, 8><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
-    case 16: k_scatter<K, 16><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
-    case 32: k_scatter<K, 32><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets); break;
+    case 0: k_scatter<K, 0><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
+    case 4: k_scatter<K, 4><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 8: k_scatter<K, 8><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 16: k_scatter<K, 16><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 32: k_scatter<K, 32><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
     default: return COL_EINVAL;
     }
     COL_LAUNCH_OK();
@@ -316,6 +326,8 @@ inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
 }  // namespace
 
 extern "C" {
+
+void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
 uint32_t col_radix_tile(int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return TILE; }
 

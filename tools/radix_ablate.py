@@ -1,0 +1,34 @@
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from collision_amd import hip
+from collision_amd._lib import call, cdll
+import bench
+ctx = hip.Context(); cq = hip.CommandQueue(ctx)
+n = 1 << 26
+rng = np.random.RandomState(4)
+keys = rng.randint(0, 2 ** 30, size=n).astype(np.uint32)
+kin, vin = hip.Buffer(ctx, hostbuf=keys), hip.Buffer(ctx, hostbuf=np.arange(n, dtype=np.uint32))
+kout, vout = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+tile = call.col_radix_tile(4, 4); nb = -(-n // tile)
+hist = hip.Buffer(ctx, 256 * nb * 4)
+ss = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb))
+call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
+call.col_scan_u32(cq.stream, hist.ptr, 256 * nb, ss.ptr)
+def copy():
+    call.col_memcpy_d2d(cq.stream, kout.ptr, kin.ptr, n * 4); call.col_memcpy_d2d(cq.stream, vout.ptr, vin.ptr, n * 4)
+copy(); cq.finish()
+ms = bench.time_events(hip, cq, copy, 5)
+print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
+for mode, what in ((0, "full (XCD-aware tiles)"), (4, "full, blockIdx order"), (2, "rank + coalesced write"), (0, "full (XCD-aware tiles)")):
+    cdll().col_debug_radix(mode)
+    def run():
+        call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
+    run(); cq.finish()
+    ms = bench.time_events(hip, cq, run, 5)
+    print("mode %d %-26s %.4f ms  %.0f GB/s" % (mode, what, ms, n * 16 / ms / 1e6))
+cdll().col_debug_radix(0)
+def h():
+    call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
+h(); cq.finish()
+ms = bench.time_events(hip, cq, h, 5); print("hist %.4f ms %.0f GB/s" % (ms, n * 4 / ms / 1e6))
