@@ -98,6 +98,21 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
     }
 
 
+def pmc_traffic():
+    """HBM bytes per k_scatter launch from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of tools/radix_only.py, summarised by tools/summarize_prof.py).
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a coalesced
+    streaming read -- checked here on k_hist, which reads exactly n*4 bytes and reports n*2 -- so
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  None if the summary is not present."""
+    f = ROOT / "profiles" / "r01_radix64M_pmc.json"
+    if not f.exists():
+        return None
+    d = json.loads(f.read_text()).get("k_scatter<unsigned int, 4>")
+    if not d or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        return None
+    return (2.0 * d["FETCH_SIZE"]["median"] + d["WRITE_SIZE"]["median"]) * 1024.0
+
+
 def cpu_baseline(coords, radii, budget_s=12.0, max_runs=20):
     """The CPU oracle (C port of the path, 1 thread) on the same 1 M scene, repeated for ~budget_s."""
     import oracle
@@ -234,7 +249,8 @@ def main():
                         "achieved": round(rb["scatter_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(rb["scatter_gbs"] / HBM_PEAK_GBS, 4),
                         "algo_bytes_per_launch": rb["algo_bytes_per_launch"],
-                        "launch_ms": round(rb["scatter_ms"], 4), "traffic": None}
+                        "launch_ms": round(rb["scatter_ms"], 4), "traffic": pmc_traffic(),
+                        "traffic_source": "profiles/r01_radix64M_pmc.json (rocprofv3 --pmc, offline pass)"}
         if world == 1:
             # per-stage device times of the 1M path (HIP events on the launch stream)
             from collision_amd.stages import stage_times

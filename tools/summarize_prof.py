@@ -1,0 +1,48 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC counter_collection) into small text/JSON
+summaries that are committed under profiles/.
+
+    python tools/summarize_prof.py stats  <kernel_stats.csv>              > profiles/xxx_kernel_stats.txt
+    python tools/summarize_prof.py pmc    <counter_collection.csv> [...]  > profiles/xxx_pmc.json
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    print("%-44s %7s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+    for r in rows:
+        print("%-44s %7s %12.2f %12.2f %12.2f %7.2f" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                       float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                       float(r["Percentage"])))
+
+
+def pmc(paths):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for kern, counters in agg.items():
+        out[kern] = {}
+        for c, v in counters.items():
+            v.sort()
+            out[kern][c] = {"launches": len(v), "median": v[len(v) // 2], "min": v[0], "max": v[-1]}
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
