@@ -73,6 +73,15 @@ _PROTOS = {
     "col_collide": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_pack_spheres": (None, [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]),
+    "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "col_select_overlap": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "col_traverse_ghost": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_debug_traverse": (C.c_int, [C.c_int]),
+    "col_debug_lbvh": (C.c_int, [C.c_int]),
+    "col_debug_radix": (C.c_int, [C.c_int]),
     "col_gather": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "col_scatter": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "col_find_offsets": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),

@@ -1,0 +1,171 @@
+// Device pieces of the multi-GPU path (nothing in the reference to mirror:
+// it is single-device).  One process per GPU; the collectives (AABB all-gather, sphere
+// repartition, halo exchange) are RCCL calls made by the host code in collision_amd/multi.py on
+// the same stream; the kernels here prepare and consume the exchanged buffers:
+//
+//   col_pack_spheres      rows (x, y, z, r) + global ids, optionally gathered through an index list
+//   col_unpack_radii      r lane of packed rows -> radii array
+//   col_select_overlap    compact the indices of spheres whose box overlaps a peer's scene AABB
+//                         (the halo: what a peer needs to see of this rank's spheres)
+//   col_traverse_ghost    ghost spheres from other ranks as QUERIES against the local LBVH
+//                         (they are never inserted); emits (ghost global id, local global id)
+//   col_translate_pairs   local sphere indices -> global ids for the pairs found locally
+#include "col_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr u32 END = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ coords, const float *__restrict__ radii,
+                                               const u32 *__restrict__ gids, const u32 *__restrict__ idx, u32 n,
+                                               float4 *__restrict__ rows, u32 *__restrict__ out_gids) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 s = idx ? idx[i] : i;
+    float4 c = coords[s];
+    if (radii) c.w = radii[s];
+    rows[i] = c;
+    if (out_gids) out_gids[i] = gids ? gids[s] : s;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_radii(const float4 *__restrict__ rows, u32 n, float *__restrict__ radii) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) radii[i] = rows[i].w;
+}
+
+// rows carry the radius in lane w.  aabb = (lo.xyz, -, hi.xyz, -).  Appends matching indices to
+// out (one atomic per wave); order is not preserved.
+__global__ __launch_bounds__(256) void k_select(const float4 *__restrict__ rows, u32 n, const float4 *__restrict__ aabb,
+                                                 u32 *__restrict__ out, u32 *__restrict__ count) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (i < n) {
+        const float4 c = rows[i], lo = aabb[0], hi = aabb[1];
+        hit = c.x + c.w > lo.x && c.x - c.w < hi.x && c.y + c.w > lo.y && c.y - c.w < hi.y &&
+              c.z + c.w > lo.z && c.z - c.w < hi.z;               // strict, as collision.cl:164-166
+    }
+    const u64 hits = __ballot(hit);
+    if (!hits) return;
+    const u32 lane = lane_id();
+    const int leader = (int)__builtin_ctzll(hits);
+    u32 base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (u32)__popcll(hits));
+    base = __shfl(base, leader, COL_WAVE);
+    if (hit) out[base + mbcnt(hits)] = i;
+}
+
+// Lane-per-ghost walk from the root over the 32-byte records (box + skip/down links, bvh.hip).
+// No position pruning: every local leaf is a candidate for a ghost.
+constexpr int GW = 4, GCAP = 256;
+__global__ __launch_bounds__(GW * 64) void k_ghost(const float4 *__restrict__ ghosts, const u32 *__restrict__ ghost_gids,
+                                                   u32 n_ghost, const float4 *__restrict__ rows, u32 n,
+                                                   const u32 *__restrict__ local_gids, u32 *__restrict__ pairs,
+                                                   u32 *__restrict__ counter, u32 capacity) {
+    __shared__ uint2 s_buf[GW][GCAP];
+    const u32 lane = lane_id(), w = threadIdx.x / 64;
+    const u32 leaf_start = n - 1;
+    uint2 *buf = s_buf[w];
+    u32 staged = 0;
+    const u32 g = blockIdx.x * (GW * 64) + threadIdx.x;
+    float lx = INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;
+    u32 gid = 0, idx = END;
+    if (g < n_ghost) {
+        const float4 c = ghosts[g];
+        lx = c.x - c.w; ly = c.y - c.w; lz = c.z - c.w;          // same arithmetic as leafBounds, collision.cl:139-140
+        hx = c.x + c.w; hy = c.y + c.w; hz = c.z + c.w;
+        gid = ghost_gids[g];
+        idx = 0;
+    }
+    while (__ballot(idx != END)) {
+        bool hit = false;
+        u32 down = 0;
+        if (idx != END) {
+            const float4 a = rows[2ull * idx], b = rows[2ull * idx + 1];
+            const u32 skip = __float_as_uint(a.w);
+            down = __float_as_uint(b.w);
+            const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
+            const bool leaf = idx >= leaf_start;
+            hit = overlap && leaf;
+            idx = (overlap && !leaf) ? down : skip;
+        }
+        const u64 hits = __ballot(hit);
+        if (hits) {
+            const u32 add = (u32)__popcll(hits);
+            if (staged + add > (u32)GCAP) {      // flush this wave's staging area with one atomic
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(counter, staged);
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                for (u32 i = lane; i < staged; i += 64)
+                    if (base + i < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * (base + i)) = buf[i];
+                staged = 0;
+            }
+            if (hit) buf[staged + mbcnt(hits)] = make_uint2(gid, local_gids ? local_gids[down] : down);
+            staged += add;
+        }
+    }
+    if (staged) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(counter, staged);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        for (u32 i = lane; i < staged; i += 64)
+            if (base + i < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * (base + i)) = buf[i];
+    }
+}
+
+// pairs[first .. min(*count, capacity)) hold local indices: replace by gids[index]
+__global__ __launch_bounds__(256) void k_translate(u32 *__restrict__ pairs, const u32 *__restrict__ count, u32 first,
+                                                    u32 capacity, const u32 *__restrict__ gids) {
+    const u32 total = min(*count, capacity);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = 2ull * first + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < 2ull * total; i += stride)
+        pairs[i] = gids[pairs[i]];
+}
+
+}  // namespace
+
+extern "C" {
+
+int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids, const uint32_t *idx,
+                     uint32_t n, void *rows, uint32_t *out_gids) {
+    if (n == 0) return COL_OK;
+    k_pack<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>(
+        (const float4 *)coords, (const float *)radii, gids, idx, n, (float4 *)rows, out_gids);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii) {
+    if (n == 0) return COL_OK;
+    k_unpack_radii<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, n, (float *)radii);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out, uint32_t *count) {
+    if (n == 0) return COL_OK;
+    k_select<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, n, (const float4 *)aabb, out, count);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_traverse_ghost(void *stream, const void *ghost_rows, const uint32_t *ghost_gids, uint32_t n_ghost,
+                       const void *bounds, uint32_t n, const uint32_t *local_gids, uint32_t *pairs,
+                       uint32_t *counter, uint32_t capacity) {
+    if (n_ghost == 0 || n == 0) return COL_OK;
+    if (capacity > 0 && !pairs) return COL_EINVAL;
+    k_ghost<<<dim3((unsigned)col_ceil_div(n_ghost, GW * 64)), dim3(GW * 64), 0, col_stream(stream)>>>(
+        (const float4 *)ghost_rows, ghost_gids, n_ghost, (const float4 *)bounds, n, local_gids, pairs, counter, capacity);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first, uint32_t capacity,
+                        const uint32_t *gids) {
+    if (capacity == 0) return COL_OK;
+    k_translate<<<dim3(256), dim3(256), 0, col_stream(stream)>>>(pairs, count, first, capacity, gids);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+"""Multi-GPU broad phase: one process per GPU, torch.distributed (RCCL over xGMI) for the exchanges.
+
+New work -- the reference is single-device.  Spheres arrive partitioned by
+``hash(id) mod R`` (BASELINE config 4).  One step on every rank:
+
+1. **AABB all-gather #1** (32 B/rank): min/max of the local centres -> the global scene range, so
+   Morton codes mean the same thing on every rank.
+2. **Spatial repartition** (``partition="morton"``, default): Morton code per sphere, local radix
+   sort, R-1 splitters from gathered samples (balanced for clustered scenes too), one
+   variable-size all-to-all of packed rows ``(x, y, z, r)`` + global ids.  Each rank now owns a
+   contiguous Morton range, i.e. a compact region.  With ``partition="hash"`` this step is skipped
+   and every rank keeps its hash subset (its region is then the whole scene).
+3. **Local path**: exactly the single-GPU pipeline (``col_collide``) on the owned spheres; pair ids
+   are translated from local indices to global ids.
+4. **AABB all-gather #2**: each rank's region box (root of its LBVH, radii included).
+5. **Halo exchange**: for every peer that is responsible for the (me -> peer) direction, the
+   owned spheres whose box overlaps that peer's region box are packed and sent (all-to-all-v;
+   direct peer-to-peer over xGMI, no ring).
+6. **Ghost queries**: received spheres are QUERIES against the local tree (never inserted) and
+   emit ``(ghost id, local id)`` pairs.
+
+A cross-rank pair {a in r, b in q} is reported by exactly one side: rank r answers the ghosts of
+rank q iff ``handles(r, q, R)``.  The union over ranks of the unordered id pairs equals the
+single-GPU pair set.
+
+The device work goes through an *engine* object (``HipEngine``: the C ABI on torch CUDA tensors);
+the distributed protocol itself only needs ``torch.distributed`` and tensors on ``engine.device``,
+so the world_size-2 ``gloo`` tests drive it on the CPU with a test double for the engine.
+"""
+import numpy as np
+
+from . import hip
+from ._lib import call
+from .misc import roundUp
+
+SAMPLES = 1024          # splitter samples per rank
+
+
+def handles(r, q, world):
+    """True iff rank r answers the ghost spheres of rank q (exactly one of (r,q), (q,r) holds)."""
+    if r == q:
+        return False
+    d = (q - r) % world
+    return 2 * d < world or (2 * d == world and r < q)
+
+
+def hash_owner(gids, world):
+    """Initial owner of a sphere: a multiplicative hash of its id (BASELINE config 4)."""
+    return ((np.asarray(gids, dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(7)) % np.uint64(world)
+
+
+def make_rank_scene(n_per_rank, rank, world, radius, seed=4):
+    """Rank-local share of a (world * n_per_rank)-sphere uniform scene (RandomState(seed), as
+    BASELINE.md section 5), hash-partitioned by id.  Returns (coords4, radii, gids)."""
+    n = n_per_rank * world
+    rng = np.random.RandomState(seed)
+    coords = rng.random_sample((n, 3)).astype(np.float32)
+    gids = np.arange(n, dtype=np.uint32)
+    mine = hash_owner(gids, world) == rank
+    rows = np.zeros((int(mine.sum()), 4), np.float32)
+    rows[:, :3] = coords[mine]
+    # same contacts-per-sphere as the 1-GPU scene: shrink r with the density
+    r = np.float32(radius * (1.0 / world) ** (1.0 / 3.0))
+    return rows, np.full(len(rows), r, np.float32), gids[mine]
+
+
+# --------------------------------------------------------------------------- exchange layer
+class Exchange:
+    """The three collectives of the path on tensors of ``device``.  With the ``gloo`` backend
+    (CPU tests, or several ranks sharing one GPU in rehearsals) device tensors are staged through
+    the host; with ``nccl`` (= RCCL) they go device to device."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.stage = dist.get_backend() != "nccl" and device.type != "cpu"
+
+    def all_gather(self, t):
+        """[...] -> [world, ...]"""
+        torch = self.torch
+        src = t.cpu() if self.stage else t.contiguous()
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(out, src)
+        return torch.stack(out).to(self.device)
+
+    def exchange_counts(self, send_counts):
+        """send_counts[q] = rows I send to q  ->  recv_counts[q] = rows q sends to me."""
+        torch = self.torch
+        mat = self.all_gather(torch.tensor(send_counts, dtype=torch.int64, device=self.device))
+        return [int(x) for x in mat[:, self.rank].cpu().tolist()]
+
+    def all_to_all_v(self, send, send_counts, recv, recv_counts):
+        """Rows grouped by destination in `send`, received grouped by source into `recv`."""
+        torch, dist = self.torch, self.dist
+        ns, nr = sum(send_counts), sum(recv_counts)
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(recv[:nr], send[:ns], list(recv_counts), list(send_counts))
+            return
+        s = send[:ns].cpu() if self.stage else send[:ns]
+        r = torch.empty((nr,) + tuple(send.shape[1:]), dtype=send.dtype)
+        so = np.concatenate([[0], np.cumsum(send_counts)]).astype(int)
+        ro = np.concatenate([[0], np.cumsum(recv_counts)]).astype(int)
+        r[ro[self.rank]:ro[self.rank + 1]] = s[so[self.rank]:so[self.rank + 1]]
+        ops = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            if send_counts[q]:
+                ops.append(dist.P2POp(dist.isend, s[so[q]:so[q + 1]].contiguous(), q))
+            if recv_counts[q]:
+                ops.append(dist.P2POp(dist.irecv, r[ro[q]:ro[q + 1]], q))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        recv[:nr] = r.to(recv.device)
+
+    def all_reduce_sum(self, value):
+        torch = self.torch
+        t = torch.tensor([value], dtype=torch.int64)
+        if self.dist.get_backend() == "nccl":
+            t = t.to(self.device)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+
+# --------------------------------------------------------------------------- device engine
+class HipEngine:
+    """Device work of one rank through the C ABI, on torch CUDA tensors (torch = memory + stream)."""
+
+    def __init__(self, ctx, capacity, group_size, pair_capacity, ghost_capacity):
+        import torch
+        from .collision import Collider
+        self.torch = torch
+        self.ctx = ctx
+        self.device = torch.device("cuda", ctx.device)
+        torch.cuda.set_device(self.device)
+        self.cq = hip.CommandQueue(ctx, stream=torch.cuda.current_stream().cuda_stream)
+        self.capacity, self.pair_capacity, self.ghost_capacity = capacity, pair_capacity, ghost_capacity
+        self.group_size = group_size
+        f32, i32 = torch.float32, torch.int32
+        dev = self.device
+
+        def rows(n):
+            return torch.zeros((n, 4), dtype=f32, device=dev)
+
+        def ints(n):
+            return torch.zeros(n, dtype=i32, device=dev)
+
+        self.rows_in, self.gids_in = rows(capacity), ints(capacity)
+        self.codes, self.codes_sorted, self.iota, self.perm = ints(capacity), ints(capacity), ints(capacity), ints(capacity)
+        self.send_rows, self.send_gids = rows(capacity), ints(capacity)
+        self.owned_rows, self.owned_gids = rows(capacity), ints(capacity)
+        self.radii = torch.zeros(capacity, dtype=f32, device=dev)
+        self.sel_idx, self.sel_count = ints(capacity), ints(1)
+        self.halo_rows, self.halo_gids = rows(ghost_capacity), ints(ghost_capacity)
+        self.ghost_rows, self.ghost_gids = rows(ghost_capacity), ints(ghost_capacity)
+        self.pairs = torch.zeros((pair_capacity, 2), dtype=i32, device=dev)
+        self.counter = ints(1)
+        self.range8 = torch.zeros(8, dtype=f32, device=dev)
+        self.box8 = torch.zeros(8, dtype=f32, device=dev)
+        self.collider = Collider(ctx, capacity, 64, group_size)
+        self.collider._allocate()
+        self._reduce_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(0, 4))
+        self._sort_scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(capacity, 4, 4))
+        self.n_owned = 0
+
+    # -- inputs
+    def load(self, coords4, radii, gids):
+        torch = self.torch
+        n = len(coords4)
+        if n > self.capacity:
+            raise ValueError("rank capacity %d < %d local spheres" % (self.capacity, n))
+        host = np.array(coords4, dtype=np.float32, copy=True)
+        host[:, 3] = radii
+        self.rows_in[:n] = torch.from_numpy(host).to(self.device)
+        self.gids_in[:n] = torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32)).to(self.device)
+        return n
+
+    # -- steps (all asynchronous on the current torch stream)
+    def centre_range(self, rows, n):
+        """min / max rows (lane w is the radius range, ignored) -> tensor[8]."""
+        if n == 0:
+            self.range8[:4] = float("inf")
+            self.range8[4:] = float("-inf")
+        else:
+            call.col_reduce(self.cq.stream, rows.data_ptr(), n, 0, 4, 0, self._reduce_scratch.ptr, self.range8.data_ptr())
+        return self.range8
+
+    def sort_by_code(self, rows, n, range8):
+        s = self.cq.stream
+        call.col_morton(s, rows.data_ptr(), range8.data_ptr(), n, n, 4, self.codes.data_ptr(), self.iota.data_ptr())
+        call.col_radix_sort(s, self.codes.data_ptr(), self.codes_sorted.data_ptr(), self.iota.data_ptr(),
+                            self.perm.data_ptr(), n, 4, 4, self._sort_scratch.ptr, 0)
+        return self.codes_sorted, self.perm
+
+    def pack(self, rows, gids, idx, n, out_rows, out_gids, out_offset=0):
+        call.col_pack_spheres(self.cq.stream, rows.data_ptr(), None, gids.data_ptr(),
+                              None if idx is None else idx.data_ptr(), n,
+                              out_rows.data_ptr() + 16 * out_offset, out_gids.data_ptr() + 4 * out_offset)
+
+    def collide(self, rows, gids, n):
+        """Single-GPU path on the owned spheres; pairs come out as global ids."""
+        s = self.cq.stream
+        self.n_owned = n
+        self.counter.zero_()
+        if n == 0:
+            return
+        c = self.collider
+        call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
+        call.col_collide(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), 4,
+                         c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
+                         c._nodes_buf.ptr, c._bounds_buf.ptr, c._flags_buf.ptr, c._alloc["scratch"].ptr,
+                         self.counter.data_ptr(), self.pairs.data_ptr(), self.pair_capacity)
+        call.col_translate_pairs(s, self.pairs.data_ptr(), self.counter.data_ptr(), 0, self.pair_capacity,
+                                 gids.data_ptr())
+
+    def region_box(self):
+        """Box of everything this rank owns = root of its tree (lo.xyz, -, hi.xyz, -)."""
+        if self.n_owned == 0:
+            self.box8[:4] = float("inf")
+            self.box8[4:] = float("-inf")
+        else:
+            call.col_memcpy_d2d(self.cq.stream, self.box8.data_ptr(), self.collider._bounds_buf.ptr, 32)
+        return self.box8
+
+    def select(self, rows, n, box8):
+        """Indices of owned spheres whose box overlaps box8 -> (index tensor, count); syncs."""
+        self.sel_count.zero_()
+        call.col_select_overlap(self.cq.stream, rows.data_ptr(), n, box8.data_ptr(), self.sel_idx.data_ptr(),
+                                self.sel_count.data_ptr())
+        return self.sel_idx, int(self.sel_count.item())
+
+    def ghost_queries(self, rows, gids, n_ghost, owned_gids):
+        if self.n_owned == 0 or n_ghost == 0:
+            return
+        call.col_traverse_ghost(self.cq.stream, rows.data_ptr(), gids.data_ptr(), n_ghost,
+                                self.collider._bounds_buf.ptr, self.n_owned, owned_gids.data_ptr(),
+                                self.pairs.data_ptr(), self.counter.data_ptr(), self.pair_capacity)
+
+    def pair_count(self):
+        return int(self.counter.item()) & 0xFFFFFFFF
+
+    def read_pairs(self):
+        n = min(self.pair_count(), self.pair_capacity)
+        return self.pairs[:n].cpu().numpy().view(np.uint32)
+
+    def synchronize(self):
+        self.torch.cuda.current_stream().synchronize()
+
+
+# --------------------------------------------------------------------------- the protocol
+class DistributedCollider:
+    def __init__(self, ctx, dist, n_local, group_size=256, pair_capacity=1 << 19, partition="morton",
+                 slack=1.6, engine=None):
+        if partition not in ("morton", "hash"):
+            raise ValueError("partition must be 'morton' or 'hash'")
+        self.dist, self.partition = dist, partition
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        capacity = roundUp(int(n_local * slack) + 4096, 2 * group_size)
+        # hash partition: a rank answers about half of everybody else's spheres
+        ghost_capacity = capacity * (max(1, self.world // 2) if partition == "hash" else 1)
+        self.engine = engine or HipEngine(ctx, capacity, group_size, pair_capacity, ghost_capacity)
+        self.capacity, self.ghost_capacity = capacity, ghost_capacity
+        self.x = Exchange(dist, self.engine.device)
+        self.cq = getattr(self.engine, "cq", None)
+        self.n_in = 0
+        self.stats = {}
+
+    def set_local_spheres(self, coords4, radii, gids):
+        self.n_in = self.engine.load(coords4, radii, gids)
+
+    # -- one step ------------------------------------------------------------------------------
+    def step(self):
+        e, x, R, r = self.engine, self.x, self.world, self.rank
+        torch = x.torch
+        rows, gids, n = e.rows_in, e.gids_in, self.n_in
+
+        # 1. global scene range of the centres (AABB all-gather #1)
+        ranges = x.all_gather(e.centre_range(rows, n))                 # [R, 8]
+        grange = torch.cat([ranges[:, :4].min(dim=0).values, ranges[:, 4:].max(dim=0).values]).contiguous()
+
+        # 2. spatial repartition
+        if self.partition == "morton" and R > 1:
+            codes, perm = e.sort_by_code(rows, n, grange)
+            splitters = self._splitters(codes, n)
+            bounds = torch.searchsorted(codes[:n].to(torch.int64), splitters)      # codes < 2^30
+            edges = [0] + [int(v) for v in bounds.cpu().tolist()] + [n]
+            send_counts = [edges[q + 1] - edges[q] for q in range(R)]
+            e.pack(rows, gids, perm, n, e.send_rows, e.send_gids)
+            recv_counts = x.exchange_counts(send_counts)
+            m = sum(recv_counts)
+            if m > self.capacity:
+                raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
+            x.all_to_all_v(e.send_rows, send_counts, e.owned_rows, recv_counts)
+            x.all_to_all_v(e.send_gids, send_counts, e.owned_gids, recv_counts)
+            own_rows, own_gids = e.owned_rows, e.owned_gids
+        else:
+            own_rows, own_gids, m = rows, gids, n
+        self.stats["owned"] = m
+
+        # 3. the single-GPU path on the owned spheres
+        e.collide(own_rows, own_gids, m)
+        if R == 1:
+            return
+
+        # 4. region boxes (AABB all-gather #2)
+        boxes = x.all_gather(e.region_box())                           # [R, 8]
+
+        # 5. halo exchange: my boundary spheres go to the peers that answer for me
+        send_counts, off = [0] * R, 0
+        for q in range(R):
+            if not handles(q, r, R):
+                continue
+            idx, cnt = e.select(own_rows, m, boxes[q].contiguous())
+            if off + cnt > self.ghost_capacity:
+                raise RuntimeError("halo of rank %d exceeds its capacity %d" % (r, self.ghost_capacity))
+            e.pack(own_rows, own_gids, idx, cnt, e.halo_rows, e.halo_gids, off)
+            send_counts[q] = cnt
+            off += cnt
+        recv_counts = x.exchange_counts(send_counts)
+        g = sum(recv_counts)
+        if g > self.ghost_capacity:
+            raise RuntimeError("rank %d would receive %d ghosts > capacity %d" % (r, g, self.ghost_capacity))
+        x.all_to_all_v(e.halo_rows, send_counts, e.ghost_rows, recv_counts)
+        x.all_to_all_v(e.halo_gids, send_counts, e.ghost_gids, recv_counts)
+        self.stats["ghosts"] = g
+
+        # 6. ghosts as queries against my tree
+        e.ghost_queries(e.ghost_rows, e.ghost_gids, g, own_gids)
+
+    def _splitters(self, sorted_codes, n):
+        """R-1 global quantiles of the Morton codes from SAMPLES evenly spaced local samples."""
+        torch, R = self.x.torch, self.world
+        if n > 0:
+            pos = torch.linspace(0, n - 1, SAMPLES, device=sorted_codes.device).long()
+            sample = sorted_codes[pos].to(torch.int64)
+        else:
+            sample = torch.full((SAMPLES,), 1 << 30, dtype=torch.int64, device=sorted_codes.device)
+        allsamp = self.x.all_gather(sample).reshape(-1).sort().values
+        cut = (torch.arange(1, R, device=allsamp.device) * (allsamp.numel() // R)).long()
+        return allsamp[cut].contiguous()
+
+    # -- results -------------------------------------------------------------------------------
+    def synchronize(self):
+        self.engine.synchronize()
+
+    def local_pair_count(self):
+        return self.engine.pair_count()
+
+    def global_pair_count(self):
+        return self.x.all_reduce_sum(self.engine.pair_count())
+
+    def local_pairs(self):
+        """(count, 2) uint32 global ids found by this rank (local x local, then ghost x local)."""
+        return self.engine.read_pairs()

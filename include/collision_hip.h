@@ -159,6 +159,9 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 
 /* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
  * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
+void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query */
+void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
+void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order */
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                        const void *bounds, uint32_t n, int coord_bytes, uint64_t *stats, int mode);
 
@@ -182,6 +185,25 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
                 int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
                 col_node *nodes, void *bounds, uint32_t *flags, void *scratch,
                 uint32_t *counter, uint32_t *pairs, uint32_t capacity);
+
+/* ---------------------------------------------------------------- multi-GPU helpers
+ * New work (the reference is single-device): device side of the sphere
+ * repartition / halo exchange / ghost queries driven by collision_amd/multi.py over RCCL.
+ * f32 coordinates only.  Packed rows are (x, y, z, r). */
+int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids,
+                     const uint32_t *idx, uint32_t n, void *rows, uint32_t *out_gids);
+int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii);
+/* indices of rows whose box strictly overlaps aabb (2 x vec4) appended to out; *count zeroed by caller */
+int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out,
+                       uint32_t *count);
+/* ghost spheres as queries against the local tree (bounds with links); emits
+ * (ghost gid, local_gids[hit]); counter is NOT reset (it continues the local pair list) */
+int col_traverse_ghost(void *stream, const void *ghost_rows, const uint32_t *ghost_gids,
+                       uint32_t n_ghost, const void *bounds, uint32_t n, const uint32_t *local_gids,
+                       uint32_t *pairs, uint32_t *counter, uint32_t capacity);
+/* pairs[first .. min(*count, capacity)) : index -> gids[index] */
+int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first,
+                        uint32_t capacity, const uint32_t *gids);
 
 /* ---------------------------------------------------------------- index / offset
  * collision/index.cl:1-13 (Indexer.gather/scatter, index.py:23-55) and
