@@ -29,6 +29,51 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ coords,
     if (out_gids) out_gids[i] = gids ? gids[s] : s;
 }
 
+// Transport record for the exchanges: 5 words (x, y, z, r, global id), so that one all-to-all
+// moves everything a peer needs about a sphere.
+__global__ __launch_bounds__(256) void k_pack5(const float4 *__restrict__ rows, const u32 *__restrict__ gids,
+                                                const u32 *__restrict__ idx, u32 n, u32 *__restrict__ rec) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 s = idx ? idx[i] : i;
+    const float4 c = rows[s];
+    u32 *o = rec + 5ull * i;
+    o[0] = __float_as_uint(c.x); o[1] = __float_as_uint(c.y); o[2] = __float_as_uint(c.z); o[3] = __float_as_uint(c.w);
+    o[4] = gids ? gids[s] : s;
+}
+__global__ __launch_bounds__(256) void k_unpack5(const u32 *__restrict__ rec, u32 n, float4 *__restrict__ rows,
+                                                  u32 *__restrict__ gids, float *__restrict__ radii) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 *o = rec + 5ull * i;
+    const float4 c = make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]), __uint_as_float(o[3]));
+    rows[i] = c;
+    gids[i] = o[4];
+    if (radii) radii[i] = c.w;
+}
+
+// Halo selection against up to 8 peer boxes in one launch: list[k] collects the indices of the
+// spheres overlapping boxes[k] (k-th handled peer), counts[k] their number.
+struct PeerBoxes { float lo[8][3]; float hi[8][3]; int n; };
+__global__ __launch_bounds__(256) void k_select_multi(const float4 *__restrict__ rows, u32 n, PeerBoxes pb, u32 stride,
+                                                       u32 *__restrict__ lists, u32 *__restrict__ counts) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) c = rows[i];
+    const u32 lane = lane_id();
+    for (int k = 0; k < pb.n; k++) {
+        const bool hit = i < n && c.x + c.w > pb.lo[k][0] && c.x - c.w < pb.hi[k][0] && c.y + c.w > pb.lo[k][1] &&
+                         c.y - c.w < pb.hi[k][1] && c.z + c.w > pb.lo[k][2] && c.z - c.w < pb.hi[k][2];
+        const u64 hits = __ballot(hit);
+        if (!hits) continue;
+        const int leader = (int)__builtin_ctzll(hits);
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counts[k], (u32)__popcll(hits));
+        base = __shfl(base, leader, COL_WAVE);
+        if (hit) lists[(uint64_t)k * stride + base + mbcnt(hits)] = i;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_unpack_radii(const float4 *__restrict__ rows, u32 n, float *__restrict__ radii) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) radii[i] = rows[i].w;
@@ -131,6 +176,33 @@ int col_pack_spheres(void *stream, const void *coords, const void *radii, const 
     if (n == 0) return COL_OK;
     k_pack<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>(
         (const float4 *)coords, (const float *)radii, gids, idx, n, (float4 *)rows, out_gids);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_pack5(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec) {
+    if (n == 0) return COL_OK;
+    k_pack5<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, gids, idx, n, (u32 *)rec);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii) {
+    if (n == 0) return COL_OK;
+    k_unpack5<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const u32 *)rec, n, (float4 *)rows, gids, (float *)radii);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const float *boxes, int n_boxes,
+                             uint32_t stride, uint32_t *lists, uint32_t *counts) {
+    if (n_boxes < 0 || n_boxes > 8) return COL_EINVAL;
+    if (n == 0 || n_boxes == 0) return COL_OK;
+    PeerBoxes pb;
+    pb.n = n_boxes;
+    for (int k = 0; k < n_boxes; k++)
+        for (int a = 0; a < 3; a++) { pb.lo[k][a] = boxes[8 * k + a]; pb.hi[k][a] = boxes[8 * k + 4 + a]; }
+    k_select_multi<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, n, pb, stride, lists, counts);
     COL_LAUNCH_OK();
     return COL_OK;
 }

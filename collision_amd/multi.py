@@ -79,6 +79,10 @@ class Exchange:
     def all_gather(self, t):
         """[...] -> [world, ...]"""
         torch = self.torch
+        if self.dist.get_backend() == "nccl":
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t.contiguous())
+            return out
         src = t.cpu() if self.stage else t.contiguous()
         out = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(out, src)
@@ -149,11 +153,15 @@ class HipEngine:
 
         self.rows_in, self.gids_in = rows(capacity), ints(capacity)
         self.codes, self.codes_sorted, self.iota, self.perm = ints(capacity), ints(capacity), ints(capacity), ints(capacity)
-        self.send_rows, self.send_gids = rows(capacity), ints(capacity)
+        def recs(n):
+            return torch.zeros((n, 5), dtype=i32, device=dev)       # transport records (x, y, z, r, gid)
+
+        self.send5, self.recv5 = recs(capacity), recs(capacity)
         self.owned_rows, self.owned_gids = rows(capacity), ints(capacity)
         self.radii = torch.zeros(capacity, dtype=f32, device=dev)
-        self.sel_idx, self.sel_count = ints(capacity), ints(1)
-        self.halo_rows, self.halo_gids = rows(ghost_capacity), ints(ghost_capacity)
+        self.max_peers = 8
+        self.sel_lists, self.sel_counts = ints(self.max_peers * capacity), ints(self.max_peers)
+        self.halo5, self.ghost5 = recs(ghost_capacity), recs(ghost_capacity)
         self.ghost_rows, self.ghost_gids = rows(ghost_capacity), ints(ghost_capacity)
         self.pairs = torch.zeros((pair_capacity, 2), dtype=i32, device=dev)
         self.counter = ints(1)
@@ -194,10 +202,15 @@ class HipEngine:
                             self.perm.data_ptr(), n, 4, 4, self._sort_scratch.ptr, 0)
         return self.codes_sorted, self.perm
 
-    def pack(self, rows, gids, idx, n, out_rows, out_gids, out_offset=0):
-        call.col_pack_spheres(self.cq.stream, rows.data_ptr(), None, gids.data_ptr(),
-                              None if idx is None else idx.data_ptr(), n,
-                              out_rows.data_ptr() + 16 * out_offset, out_gids.data_ptr() + 4 * out_offset)
+    def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
+        """out5[out_offset + i] = (rows[idx[idx_offset + i]], gids[...]) for i < n (idx None = identity)."""
+        call.col_pack5(self.cq.stream, rows.data_ptr(), gids.data_ptr(),
+                       None if idx is None else idx.data_ptr() + 4 * idx_offset, n,
+                       out5.data_ptr() + 20 * out_offset)
+
+    def unpack5(self, rec5, n, rows, gids, radii=None):
+        call.col_unpack5(self.cq.stream, rec5.data_ptr(), n, rows.data_ptr(), gids.data_ptr(),
+                         None if radii is None else radii.data_ptr())
 
     def collide(self, rows, gids, n):
         """Single-GPU path on the owned spheres; pairs come out as global ids."""
@@ -207,7 +220,8 @@ class HipEngine:
         if n == 0:
             return
         c = self.collider
-        call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
+        if rows is not self.owned_rows:           # owned rows come out of unpack5 with radii already split off
+            call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
         call.col_collide(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), 4,
                          c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
                          c._nodes_buf.ptr, c._bounds_buf.ptr, c._flags_buf.ptr, c._alloc["scratch"].ptr,
@@ -224,12 +238,15 @@ class HipEngine:
             call.col_memcpy_d2d(self.cq.stream, self.box8.data_ptr(), self.collider._bounds_buf.ptr, 32)
         return self.box8
 
-    def select(self, rows, n, box8):
-        """Indices of owned spheres whose box overlaps box8 -> (index tensor, count); syncs."""
-        self.sel_count.zero_()
-        call.col_select_overlap(self.cq.stream, rows.data_ptr(), n, box8.data_ptr(), self.sel_idx.data_ptr(),
-                                self.sel_count.data_ptr())
-        return self.sel_idx, int(self.sel_count.item())
+    def select_multi(self, rows, n, boxes_host):
+        """boxes_host: (k, 8) float32 on the HOST, k <= 8.  One launch, one sync.
+        Returns (lists tensor, stride, [count per box])."""
+        k = len(boxes_host)
+        self.sel_counts.zero_()
+        boxes_host = np.ascontiguousarray(boxes_host, dtype=np.float32)
+        call.col_select_overlap_multi(self.cq.stream, rows.data_ptr(), n, boxes_host.ctypes.data, k, self.capacity,
+                                      self.sel_lists.data_ptr(), self.sel_counts.data_ptr())
+        return self.sel_lists, self.capacity, [int(c) for c in self.sel_counts[:k].cpu().tolist()]
 
     def ghost_queries(self, rows, gids, n_ghost, owned_gids):
         if self.n_owned == 0 or n_ghost == 0:
@@ -287,13 +304,13 @@ class DistributedCollider:
             bounds = torch.searchsorted(codes[:n].to(torch.int64), splitters)      # codes < 2^30
             edges = [0] + [int(v) for v in bounds.cpu().tolist()] + [n]
             send_counts = [edges[q + 1] - edges[q] for q in range(R)]
-            e.pack(rows, gids, perm, n, e.send_rows, e.send_gids)
+            e.pack5(rows, gids, perm, 0, n, e.send5)
             recv_counts = x.exchange_counts(send_counts)
             m = sum(recv_counts)
             if m > self.capacity:
                 raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
-            x.all_to_all_v(e.send_rows, send_counts, e.owned_rows, recv_counts)
-            x.all_to_all_v(e.send_gids, send_counts, e.owned_gids, recv_counts)
+            x.all_to_all_v(e.send5, send_counts, e.recv5, recv_counts)
+            e.unpack5(e.recv5, m, e.owned_rows, e.owned_gids, e.radii)
             own_rows, own_gids = e.owned_rows, e.owned_gids
         else:
             own_rows, own_gids, m = rows, gids, n
@@ -308,22 +325,24 @@ class DistributedCollider:
         boxes = x.all_gather(e.region_box())                           # [R, 8]
 
         # 5. halo exchange: my boundary spheres go to the peers that answer for me
+        boxes_host = boxes.cpu().numpy()
+        peers = [q for q in range(R) if handles(q, r, R)]
         send_counts, off = [0] * R, 0
-        for q in range(R):
-            if not handles(q, r, R):
-                continue
-            idx, cnt = e.select(own_rows, m, boxes[q].contiguous())
-            if off + cnt > self.ghost_capacity:
-                raise RuntimeError("halo of rank %d exceeds its capacity %d" % (r, self.ghost_capacity))
-            e.pack(own_rows, own_gids, idx, cnt, e.halo_rows, e.halo_gids, off)
-            send_counts[q] = cnt
-            off += cnt
+        for c0 in range(0, len(peers), e.max_peers):              # one launch + one sync per 8 peers
+            chunk = peers[c0:c0 + e.max_peers]
+            lists, stride, counts = e.select_multi(own_rows, m, boxes_host[chunk])
+            for k, q in enumerate(chunk):
+                if off + counts[k] > self.ghost_capacity:
+                    raise RuntimeError("halo of rank %d exceeds its capacity %d" % (r, self.ghost_capacity))
+                e.pack5(own_rows, own_gids, lists, k * stride, counts[k], e.halo5, off)
+                send_counts[q] = counts[k]
+                off += counts[k]
         recv_counts = x.exchange_counts(send_counts)
         g = sum(recv_counts)
         if g > self.ghost_capacity:
             raise RuntimeError("rank %d would receive %d ghosts > capacity %d" % (r, g, self.ghost_capacity))
-        x.all_to_all_v(e.halo_rows, send_counts, e.ghost_rows, recv_counts)
-        x.all_to_all_v(e.halo_gids, send_counts, e.ghost_gids, recv_counts)
+        x.all_to_all_v(e.halo5, send_counts, e.ghost5, recv_counts)
+        e.unpack5(e.ghost5, g, e.ghost_rows, e.ghost_gids)
         self.stats["ghosts"] = g
 
         # 6. ghosts as queries against my tree

@@ -193,6 +193,13 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
 int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids,
                      const uint32_t *idx, uint32_t n, void *rows, uint32_t *out_gids);
 int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii);
+/* 5-word transport records (x, y, z, r, gid): one all-to-all moves a sphere */
+int col_pack5(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec);
+int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii);
+/* halo selection against n_boxes <= 8 peer boxes (HOST array of n_boxes x 8 floats: lo.xyz,-,hi.xyz,-)
+ * in one launch: lists[k*stride ...] / counts[k] per box; counts zeroed by the caller */
+int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const float *boxes, int n_boxes,
+                             uint32_t stride, uint32_t *lists, uint32_t *counts);
 /* indices of rows whose box strictly overlaps aabb (2 x vec4) appended to out; *count zeroed by caller */
 int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out,
                        uint32_t *count);

@@ -30,11 +30,15 @@ class OracleEngine:
         z4 = lambda n: torch.zeros((n, 4), dtype=torch.float32)
         zi = lambda n: torch.zeros(n, dtype=torch.int32)
         self.rows_in, self.gids_in = z4(capacity), zi(capacity)
-        self.send_rows, self.send_gids = z4(capacity), zi(capacity)
+        z5 = lambda n: torch.zeros((n, 5), dtype=torch.int32)
+        self.send5, self.recv5 = z5(capacity), z5(capacity)
         self.owned_rows, self.owned_gids = z4(capacity), zi(capacity)
-        self.halo_rows, self.halo_gids = z4(ghost_capacity), zi(ghost_capacity)
+        self.radii = torch.zeros(capacity)
+        self.halo5, self.ghost5 = z5(ghost_capacity), z5(ghost_capacity)
         self.ghost_rows, self.ghost_gids = z4(ghost_capacity), zi(ghost_capacity)
-        self.codes_sorted, self.perm, self.sel_idx = zi(capacity), zi(capacity), zi(capacity)
+        self.codes_sorted, self.perm = zi(capacity), zi(capacity)
+        self.max_peers = 8
+        self.sel_lists = zi(self.max_peers * capacity)
         self.found = []
         self.n_owned = 0
         self._boxes = None
@@ -60,10 +64,16 @@ class OracleEngine:
         self.perm[:n] = self.torch.from_numpy(perm.astype(np.int32))
         return self.codes_sorted, self.perm
 
-    def pack(self, rows, gids, idx, n, out_rows, out_gids, out_offset=0):
-        sel = slice(0, n) if idx is None else idx[:n].long()
-        out_rows[out_offset:out_offset + n] = rows[sel]
-        out_gids[out_offset:out_offset + n] = gids[sel]
+    def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
+        t = self.torch
+        sel = slice(0, n) if idx is None else idx[idx_offset:idx_offset + n].long()
+        out5[out_offset:out_offset + n, :4] = rows[sel].view(t.int32)
+        out5[out_offset:out_offset + n, 4] = gids[sel]
+
+    def unpack5(self, rec5, n, rows, gids, radii=None):
+        t = self.torch
+        rows[:n] = rec5[:n, :4].contiguous().view(t.float32)
+        gids[:n] = rec5[:n, 4]
 
     def collide(self, rows, gids, n):
         self.n_owned, self.found = n, []
@@ -86,12 +96,14 @@ class OracleEngine:
         lo, hi = self._lo.min(axis=0), self._hi.max(axis=0)
         return t.tensor([lo[0], lo[1], lo[2], 0, hi[0], hi[1], hi[2], 0], dtype=t.float32)
 
-    def select(self, rows, n, box8):
-        b = box8.numpy()
-        hit = ((self._hi > b[0:3]) & (self._lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
-        idx = np.nonzero(hit)[0].astype(np.int32)
-        self.sel_idx[:len(idx)] = self.torch.from_numpy(idx)
-        return self.sel_idx, len(idx)
+    def select_multi(self, rows, n, boxes_host):
+        counts = []
+        for k, b in enumerate(boxes_host):
+            hit = ((self._hi > b[0:3]) & (self._lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
+            idx = np.nonzero(hit)[0].astype(np.int32)
+            self.sel_lists[k * self.capacity:k * self.capacity + len(idx)] = self.torch.from_numpy(idx)
+            counts.append(len(idx))
+        return self.sel_lists, self.capacity, counts
 
     def ghost_queries(self, rows, gids, n_ghost, owned_gids):
         if self.n_owned == 0 or n_ghost == 0:
