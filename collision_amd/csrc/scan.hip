@@ -73,6 +73,55 @@ __global__ __launch_bounds__(ST) void k_scan_apply(u32 *__restrict__ data, uint6
     }
 }
 
+// Small arrays (the radix histogram of a ~1 M-element sort is 60 k counters = 31 tiles): ONE launch.
+// Every block publishes its tile sum as an 8-byte {epoch, sum} granule (one relaxed agent-scope
+// atomic store: the data is the flag, cdna_hip_programming.md guideline 16 R2), then wave 0 reads
+// the granules of all predecessor tiles in parallel (lane = predecessor) and adds them up -- a
+// look-back without a chain, so the depth is two hops whatever the tile count.  All <= 64 blocks
+// are resident at once (64 << 256 CUs), so the polls always complete; the epoch makes stale
+// granules from earlier calls invisible without a memset launch.
+constexpr u32 CHAIN_MAX_TILES = 64;
+__global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n, u64 *__restrict__ status, u32 epoch) {
+    __shared__ u32 ws[ST / COL_WAVE];
+    __shared__ u32 s_prefix;
+    const u32 b = blockIdx.x;
+    const uint64_t base = (uint64_t)b * STILE + (uint64_t)threadIdx.x * SI;
+    u32 v[SI];
+    load_items(data, base, n, v);
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < SI; k++) t += v[k];
+    u32 total;
+    u32 run = block_excl_scan<ST>(t, ws, &total);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&status[b], ((u64)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < COL_WAVE) {
+        u32 pv = 0;
+        if (threadIdx.x < b) {
+            u64 g;
+            do {
+                g = __hip_atomic_load(&status[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((u32)(g >> 32) != epoch);
+            pv = (u32)g;
+        }
+        pv = wave_sum(pv);
+        if (threadIdx.x == 0) s_prefix = pv;
+    }
+    __syncthreads();
+    run += s_prefix;
+    u32 o[SI];
+#pragma unroll
+    for (int k = 0; k < SI; k++) { o[k] = run; run += v[k]; }
+    if (base + SI <= n) {
+        *reinterpret_cast<uint4 *>(data + base) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(data + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SI; k++)
+            if (base + k < n) data[base + k] = o[k];
+    }
+}
+
 // --- the reference's two kernels with its group structure (kernel-level parity only) ---
 // scan.cl:5-30: one 64-lane wave per group of `block` elements, chunked with a carry.
 __global__ __launch_bounds__(COL_WAVE) void k_ref_local_scan(u32 *data, u32 block, u32 *block_sums) {
@@ -99,6 +148,13 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int scan_rec(hipStream_t s, u32 *data, uint64_t n, char *scratch) {
     if (n == 0) return COL_OK;
     const uint64_t nb = col_ceil_div(n, STILE);
+    if (nb > 1 && nb <= CHAIN_MAX_TILES) {
+        static u32 epoch = 0x5EED0000u;          // never reused within a process; see k_scan_chain
+        epoch++;
+        k_scan_chain<<<dim3((unsigned)nb), dim3(ST), 0, s>>>(data, (u32)n, (u64 *)scratch, epoch);
+        COL_LAUNCH_OK();
+        return COL_OK;
+    }
     if (nb == 1) {
         k_scan_apply<<<dim3(1), dim3(ST), 0, s>>>(data, n, nullptr);
         COL_LAUNCH_OK();
@@ -119,7 +175,7 @@ int scan_rec(hipStream_t s, u32 *data, uint64_t n, char *scratch) {
 extern "C" {
 
 size_t col_scan_scratch_bytes(uint64_t n) {
-    size_t total = 256;
+    size_t total = 256 + CHAIN_MAX_TILES * sizeof(u64);
     while (n > (uint64_t)STILE) {
         n = col_ceil_div(n, STILE);
         total += align256(n * sizeof(u32));
