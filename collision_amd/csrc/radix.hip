@@ -118,17 +118,47 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
 
     const u32 wbase = w * (COL_WAVE * IT) + lane;
     K key[IT];
-#pragma unroll
-    for (int k = 0; k < IT; k++) {
-        const u32 li = wbase + k * COL_WAVE;
-        key[k] = li < valid ? keys_in[tile_base + li] : (K)~(K)0;   // padding sorts last, never stored
-    }
     V val[V_LDS ? IT : 1];
-    if (V_LDS) {
+    constexpr int KV = 16 / sizeof(K);                    // keys per 16-byte load
+    if (valid == (u32)TILE && !(dbg & 8)) {
+        // Full tile: 16-byte global loads (lane l takes KV consecutive keys), transposed to the
+        // lane-striped order the ranking needs through this wave's own slice of the LDS staging
+        // area.  LDS operations of one wave execute in order, so no barrier is needed.
+        K *stage = s_keys + w * (COL_WAVE * IT);
+        const K *src = keys_in + tile_base + w * (COL_WAVE * IT);
+#pragma unroll
+        for (int j = 0; j < IT / KV; j++) {
+            const u32 o = j * (COL_WAVE * KV) + lane * KV;
+            *reinterpret_cast<uint4 *>(stage + o) = *reinterpret_cast<const uint4 *>(src + o);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < IT; k++) key[k] = stage[k * COL_WAVE + lane];
+        if (V_LDS) {
+            constexpr int VV = 16 / sizeof(V);
+            V *vstage = s_vals + w * (COL_WAVE * IT);
+            const V *vsrc = vals_in + tile_base + w * (COL_WAVE * IT);
+#pragma unroll
+            for (int j = 0; j < IT / VV; j++) {
+                const u32 o = j * (COL_WAVE * VV) + lane * VV;
+                *reinterpret_cast<uint4 *>(vstage + o) = *reinterpret_cast<const uint4 *>(vsrc + o);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < IT; k++) val[k] = vstage[k * COL_WAVE + lane];
+        }
+    } else {
 #pragma unroll
         for (int k = 0; k < IT; k++) {
             const u32 li = wbase + k * COL_WAVE;
-            if (li < valid) val[k] = vals_in[tile_base + li];
+            key[k] = li < valid ? keys_in[tile_base + li] : (K)~(K)0;   // padding sorts last, never stored
+        }
+        if (V_LDS) {
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const u32 li = wbase + k * COL_WAVE;
+                if (li < valid) val[k] = vals_in[tile_base + li];
+            }
         }
     }
     __syncthreads();

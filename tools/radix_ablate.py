@@ -20,13 +20,18 @@ def copy():
 copy(); cq.finish()
 ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
-for mode, what in ((0, "full (XCD-aware tiles)"), (4, "full, blockIdx order"), (2, "rank + coalesced write"), (0, "full (XCD-aware tiles)")):
-    cdll().col_debug_radix(mode)
-    def run():
-        call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
-    run(); cq.finish()
-    ms = bench.time_events(hip, cq, run, 5)
-    print("mode %d %-26s %.4f ms  %.0f GB/s" % (mode, what, ms, n * 16 / ms / 1e6))
+modes = ((0, "full, 16B loads via LDS"), (8, "full, dword loads"), (2, "rank + coalesced write"), (4, "blockIdx tile order"))
+times = {m: [] for m, _ in modes}
+def run():
+    call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
+for rnd in range(12):                      # interleaved rounds in one process (rule 24)
+    for mode, _ in modes:
+        cdll().col_debug_radix(mode)
+        run(); cq.finish()
+        times[mode].append(bench.time_events(hip, cq, run, 3))
+for mode, what in modes:
+    t = sorted(times[mode])
+    print("mode %d %-26s min %.4f  median %.4f ms  -> %.0f GB/s (median)" % (mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6))
 cdll().col_debug_radix(0)
 def h():
     call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
