@@ -1,18 +1,9 @@
-"""Scene bounds: per-axis min and max of the sphere centres (``collision/bounds.py:4-15``)."""
-import numpy as np
+"""Scene bounds of the sphere centres: per-axis (min, max) rows.  Public names and constructor
+signatures of the reference's bounds module (collision/bounds.py:4-15); the classes themselves
+come from reduce.specialise."""
+from .reduce import specialise
 
-from .reduce import ReductionProgram, Reducer
-
-
-class BoundsProgram(ReductionProgram):
-    accumulator = [("INFINITY", "min"), ("-INFINITY", "max")]
-
-    def __init__(self, ctx, coord_dtype=np.dtype(("float32", 3))):
-        super().__init__(ctx, coord_dtype)
-
-
-class Bounds(Reducer):
-    program_type = BoundsProgram
-
-    def __init__(self, ctx, ngroups, group_size, coord_dtype=np.dtype(("float32", 3)), program=None):
-        super().__init__(ctx, ngroups, group_size, coord_dtype, program)
+# accumulator list of collision/bounds.py:5: start at +inf / -inf, fold with min / max
+BoundsProgram, Bounds = specialise("BoundsProgram", "Bounds", [("INFINITY", "min"), ("-INFINITY", "max")],
+                                   default_dtype=("float32", 3), dtype_keyword="coord_dtype")
+BoundsProgram.__module__ = Bounds.__module__ = __name__

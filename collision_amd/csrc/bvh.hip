@@ -185,7 +185,7 @@ template <> __device__ __forceinline__ double readlane_t(double v, int l) {
 // are flushed together with one atomic for the whole block.
 constexpr int TW = 16;            // waves per block
 constexpr int TT = TW * 64;       // 1024 threads
-constexpr int CAPW = 256;         // staged pairs per wave (2 KB)
+constexpr int CAPW = 512;         // staged pairs per wave (2 KB)
 
 struct PairSink {
     uint2 *buf;        // this wave's LDS staging area

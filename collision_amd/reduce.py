@@ -66,3 +66,38 @@ class Reducer:
         call.col_reduce(cq.stream, values_buf.ptr, size, p.type_code, p.width, p.op,
                         self._scratch.ptr, output_buf.ptr)
         return hip.Event(cq)
+
+
+def specialise(program_name, reducer_name, accumulator, default_dtype=None, dtype_keyword="value_dtype"):
+    """Build the (Program, Reducer) pair for one accumulator list -- what the reference spells as
+    two small subclasses per module (bounds.py:4-15, summer.py:4-8).  `dtype_keyword` is the name
+    the constructors give their dtype argument; `default_dtype` makes it optional."""
+    accumulator = [tuple(a) for a in accumulator]
+
+    def program_init(self, ctx, *args, **kwargs):
+        dt = _pick_dtype(args, kwargs, 0, dtype_keyword, default_dtype)
+        ReductionProgram.__init__(self, ctx, dt)
+
+    program_cls = type(program_name, (ReductionProgram,), {"accumulator": accumulator, "__init__": program_init,
+                                                           "__module__": __name__})
+
+    def reducer_init(self, ctx, ngroups, group_size, *args, **kwargs):
+        dt = _pick_dtype(args, kwargs, 0, dtype_keyword, default_dtype)
+        program = args[1] if len(args) > 1 else kwargs.get("program")
+        Reducer.__init__(self, ctx, ngroups, group_size, dt, program)
+
+    reducer_cls = type(reducer_name, (Reducer,), {"program_type": program_cls, "__init__": reducer_init,
+                                                  "__module__": __name__})
+    return program_cls, reducer_cls
+
+
+def _pick_dtype(args, kwargs, position, keyword, default):
+    if len(args) > position:
+        return args[position]
+    if keyword in kwargs:
+        return kwargs[keyword]
+    if "value_dtype" in kwargs:
+        return kwargs["value_dtype"]
+    if default is None:
+        raise TypeError("missing dtype argument %r" % keyword)
+    return np.dtype(default)
