@@ -98,6 +98,60 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
     }
 
 
+def clustered_scene(n, sigma, seed=4):
+    """BASELINE config 3: 8 Gaussian clusters, centres U(0.2,0.8)^3, n/8 points each."""
+    rng = np.random.RandomState(seed)
+    centres = rng.uniform(0.2, 0.8, size=(8, 3))
+    pts = np.concatenate([rng.normal(c, sigma, size=(n // 8, 3)) for c in centres])
+    coords = np.zeros((n, 4), np.float32)
+    coords[:, :3] = pts
+    return coords, np.full(n, RADIUS, np.float32)
+
+
+def config3_leg(hip, ctx, cq, reps=5):
+    """Traversal-divergence stress: 1 M clustered spheres, sigma calibrated for ~50 AABB contacts
+    per sphere (~25 M pairs, 200 MB of output)."""
+    from collision_amd.collision import Collider
+    sigma, cap = 0.0152, 1 << 25
+    coords, radii = clustered_scene(N_SPHERES, sigma)
+    cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
+    nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
+    col = Collider(ctx, N_SPHERES, NGROUPS, GROUP_SIZE)
+
+    def run():
+        col.get_collisions(cq, cb, rb, nb, pb, cap)
+    run()
+    cq.finish()
+    ms = time_events(hip, cq, run, reps)
+    pairs = int(hip.read_buffer(cq, nb, np.uint32, 1)[0])
+    return {"workload": "BASELINE config 3: 1M spheres in 8 Gaussian clusters (sigma=%g), r=%g" % (sigma, RADIUS),
+            "ms_per_step": round(ms, 4), "m_spheres_per_s": round(N_SPHERES / ms / 1e3, 1), "pairs": pairs,
+            "contacts_per_sphere": round(2.0 * pairs / N_SPHERES, 1), "m_pairs_per_s": round(pairs / ms / 1e3, 1)}
+
+
+def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
+    """Config 5 key distributions (tests/benchmarks/test_radix.py:51-55 shapes): Gkeys/s each."""
+    from collision_amd._lib import call
+    rng = np.random.RandomState(4)
+    out = {}
+    kout, vout = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+    vin = hip.Buffer(ctx, hostbuf=np.arange(n, dtype=np.uint32))
+    scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+    for name, keys in (("uniform32", rng.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)),
+                       ("arange", np.arange(n, dtype=np.uint32))):
+        kin = hip.Buffer(ctx, hostbuf=keys)
+        for with_values in (True, False):
+            def run():
+                call.col_radix_sort(cq.stream, kin.ptr, kout.ptr, vin.ptr if with_values else None,
+                                    vout.ptr if with_values else None, n, 4, 4 if with_values else 0, scratch.ptr, 0)
+            run()
+            cq.finish()
+            ms = time_events(hip, cq, run, reps)
+            out["%s_%s" % (name, "pairs" if with_values else "keys")] = round(n / ms / 1e6, 2)
+        del kin
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per k_scatter launch from the committed rocprofv3 PMC passes (separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of tools/radix_only.py, summarised by tools/summarize_prof.py).
@@ -262,6 +316,9 @@ def main():
             from collision_amd.stages import stage_times
             extra["stage_ms"] = stage_times(hip, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_buf,
                                             PAIR_CAPACITY)
+            if not args.no_radix:
+                extra["config3_clustered"] = config3_leg(hip, ctx, cq)
+                extra["radix_sort"]["gkeys_per_s_other_distributions"] = config5_variants(hip, ctx, cq)
         cpu = None
         if not args.no_cpu and world == 1:
             cpu = cpu_baseline(coords, radii)
