@@ -76,8 +76,10 @@ _PROTOS = {
     "col_pack_spheres": (None, [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]),
     "col_pack5": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_unpack5": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_uint32,
-                                        C.c_void_p, C.c_void_p]),
+    "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_uint32, C.c_void_p, C.c_void_p]),
+    "col_pack5_lists": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
+                               C.c_uint32, C.c_void_p, C.c_uint32]),
     "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_select_overlap": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "col_traverse_ghost": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

@@ -53,17 +53,20 @@ __global__ __launch_bounds__(256) void k_unpack5(const u32 *__restrict__ rec, u3
 }
 
 // Halo selection against up to 8 peer boxes in one launch: list[k] collects the indices of the
-// spheres overlapping boxes[k] (k-th handled peer), counts[k] their number.
-struct PeerBoxes { float lo[8][3]; float hi[8][3]; int n; };
-__global__ __launch_bounds__(256) void k_select_multi(const float4 *__restrict__ rows, u32 n, PeerBoxes pb, u32 stride,
+// spheres overlapping the region box of peer q[k], counts[k] their number.  The boxes stay on the
+// device (they come straight out of the AABB all-gather): no host round trip.
+struct PeerList { int q[8]; int n; };
+__global__ __launch_bounds__(256) void k_select_multi(const float4 *__restrict__ rows, u32 n,
+                                                       const float4 *__restrict__ boxes, PeerList pl, u32 stride,
                                                        u32 *__restrict__ lists, u32 *__restrict__ counts) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) c = rows[i];
     const u32 lane = lane_id();
-    for (int k = 0; k < pb.n; k++) {
-        const bool hit = i < n && c.x + c.w > pb.lo[k][0] && c.x - c.w < pb.hi[k][0] && c.y + c.w > pb.lo[k][1] &&
-                         c.y - c.w < pb.hi[k][1] && c.z + c.w > pb.lo[k][2] && c.z - c.w < pb.hi[k][2];
+    for (int k = 0; k < pl.n; k++) {
+        const float4 lo = boxes[2 * pl.q[k]], hi = boxes[2 * pl.q[k] + 1];      // wave-uniform
+        const bool hit = i < n && c.x + c.w > lo.x && c.x - c.w < hi.x && c.y + c.w > lo.y && c.y - c.w < hi.y &&
+                         c.z + c.w > lo.z && c.z - c.w < hi.z;
         const u64 hits = __ballot(hit);
         if (!hits) continue;
         const int leader = (int)__builtin_ctzll(hits);
@@ -71,6 +74,25 @@ __global__ __launch_bounds__(256) void k_select_multi(const float4 *__restrict__
         if ((int)lane == leader) base = atomicAdd(&counts[k], (u32)__popcll(hits));
         base = __shfl(base, leader, COL_WAVE);
         if (hit) lists[(uint64_t)k * stride + base + mbcnt(hits)] = i;
+    }
+}
+
+// Pack the n_lists selection lists back to back into transport records; list sizes are read from
+// the device (counts), so the launch needs no host knowledge of them.  blockIdx.y = list.
+__global__ __launch_bounds__(256) void k_pack5_lists(const float4 *__restrict__ rows, const u32 *__restrict__ gids,
+                                                      const u32 *__restrict__ lists, u32 stride,
+                                                      const u32 *__restrict__ counts, u32 *__restrict__ rec, u32 rec_capacity) {
+    const u32 k = blockIdx.y;
+    const u32 cnt = counts[k];
+    u32 off = 0;
+    for (u32 j = 0; j < k; j++) off += counts[j];
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+        if (off + i >= rec_capacity) return;            // overflow is reported by the host from the counts
+        const u32 s = lists[(uint64_t)k * stride + i];
+        const float4 c = rows[s];
+        u32 *o = rec + 5ull * (off + i);
+        o[0] = __float_as_uint(c.x); o[1] = __float_as_uint(c.y); o[2] = __float_as_uint(c.z); o[3] = __float_as_uint(c.w);
+        o[4] = gids[s];
     }
 }
 
@@ -194,15 +216,26 @@ int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t 
     return COL_OK;
 }
 
-int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const float *boxes, int n_boxes,
-                             uint32_t stride, uint32_t *lists, uint32_t *counts) {
-    if (n_boxes < 0 || n_boxes > 8) return COL_EINVAL;
-    if (n == 0 || n_boxes == 0) return COL_OK;
-    PeerBoxes pb;
-    pb.n = n_boxes;
-    for (int k = 0; k < n_boxes; k++)
-        for (int a = 0; a < 3; a++) { pb.lo[k][a] = boxes[8 * k + a]; pb.hi[k][a] = boxes[8 * k + 4 + a]; }
-    k_select_multi<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, n, pb, stride, lists, counts);
+int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
+                             int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts) {
+    if (n_peers < 0 || n_peers > 8) return COL_EINVAL;
+    if (n == 0 || n_peers == 0) return COL_OK;
+    PeerList pl;
+    pl.n = n_peers;
+    for (int k = 0; k < n_peers; k++) pl.q[k] = peers[k];
+    k_select_multi<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>(
+        (const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
+                    const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity) {
+    if (n_lists <= 0 || max_per_list == 0) return COL_OK;
+    unsigned gx = (unsigned)col_ceil_div(max_per_list, 256);
+    if (gx > 1024) gx = 1024;
+    k_pack5_lists<<<dim3(gx, (unsigned)n_lists), dim3(256), 0, col_stream(stream)>>>(
+        (const float4 *)rows, gids, lists, stride, counts, (u32 *)rec, rec_capacity);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -27,6 +27,8 @@ The device work goes through an *engine* object (``HipEngine``: the C ABI on tor
 the distributed protocol itself only needs ``torch.distributed`` and tensors on ``engine.device``,
 so the world_size-2 ``gloo`` tests drive it on the CPU with a test double for the engine.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import hip
@@ -88,11 +90,11 @@ class Exchange:
         self.dist.all_gather(out, src)
         return torch.stack(out).to(self.device)
 
-    def exchange_counts(self, send_counts):
-        """send_counts[q] = rows I send to q  ->  recv_counts[q] = rows q sends to me."""
-        torch = self.torch
-        mat = self.all_gather(torch.tensor(send_counts, dtype=torch.int64, device=self.device))
-        return [int(x) for x in mat[:, self.rank].cpu().tolist()]
+    def exchange_counts(self, send_counts_dev):
+        """send_counts_dev: device tensor [world], entry q = rows I send to q.  One all-gather and one
+        host sync give both directions: (send_counts, recv_counts) as Python lists."""
+        mat = self.all_gather(send_counts_dev.to(self.torch.int64)).cpu()
+        return [int(v) for v in mat[self.rank].tolist()], [int(v) for v in mat[:, self.rank].tolist()]
 
     def all_to_all_v(self, send, send_counts, recv, recv_counts):
         """Rows grouped by destination in `send`, received grouped by source into `recv`."""
@@ -238,15 +240,18 @@ class HipEngine:
             call.col_memcpy_d2d(self.cq.stream, self.box8.data_ptr(), self.collider._bounds_buf.ptr, 32)
         return self.box8
 
-    def select_multi(self, rows, n, boxes_host):
-        """boxes_host: (k, 8) float32 on the HOST, k <= 8.  One launch, one sync.
-        Returns (lists tensor, stride, [count per box])."""
-        k = len(boxes_host)
+    def select_multi(self, rows, n, boxes_dev, peers):
+        """Halo lists for up to 8 peers in one launch; boxes_dev = the gathered [world, 8] region boxes
+        (device).  Returns (lists, stride, counts) -- all on the device, no sync."""
         self.sel_counts.zero_()
-        boxes_host = np.ascontiguousarray(boxes_host, dtype=np.float32)
-        call.col_select_overlap_multi(self.cq.stream, rows.data_ptr(), n, boxes_host.ctypes.data, k, self.capacity,
-                                      self.sel_lists.data_ptr(), self.sel_counts.data_ptr())
-        return self.sel_lists, self.capacity, [int(c) for c in self.sel_counts[:k].cpu().tolist()]
+        arr = (C.c_int * len(peers))(*peers)
+        call.col_select_overlap_multi(self.cq.stream, rows.data_ptr(), n, boxes_dev.data_ptr(), arr, len(peers),
+                                      self.capacity, self.sel_lists.data_ptr(), self.sel_counts.data_ptr())
+        return self.sel_lists, self.capacity, self.sel_counts
+
+    def pack5_lists(self, rows, gids, lists, stride, counts_dev, n_lists, n, out5):
+        call.col_pack5_lists(self.cq.stream, rows.data_ptr(), gids.data_ptr(), lists.data_ptr(), stride,
+                             counts_dev.data_ptr(), n_lists, n, out5.data_ptr(), self.ghost_capacity)
 
     def ghost_queries(self, rows, gids, n_ghost, owned_gids):
         if self.n_owned == 0 or n_ghost == 0:
@@ -301,11 +306,10 @@ class DistributedCollider:
         if self.partition == "morton" and R > 1:
             codes, perm = e.sort_by_code(rows, n, grange)
             splitters = self._splitters(codes, n)
-            bounds = torch.searchsorted(codes[:n].to(torch.int64), splitters)      # codes < 2^30
-            edges = [0] + [int(v) for v in bounds.cpu().tolist()] + [n]
-            send_counts = [edges[q + 1] - edges[q] for q in range(R)]
+            edges = torch.searchsorted(codes[:n].to(torch.int64), splitters)       # codes < 2^30
+            edges = torch.cat([edges.new_zeros(1), edges, edges.new_full((1,), n)])
             e.pack5(rows, gids, perm, 0, n, e.send5)
-            recv_counts = x.exchange_counts(send_counts)
+            send_counts, recv_counts = x.exchange_counts(edges[1:] - edges[:-1])   # the step's 1st host sync
             m = sum(recv_counts)
             if m > self.capacity:
                 raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
@@ -321,26 +325,23 @@ class DistributedCollider:
         if R == 1:
             return
 
-        # 4. region boxes (AABB all-gather #2)
+        # 4. region boxes (AABB all-gather #2); they stay on the device
         boxes = x.all_gather(e.region_box())                           # [R, 8]
 
         # 5. halo exchange: my boundary spheres go to the peers that answer for me
-        boxes_host = boxes.cpu().numpy()
         peers = [q for q in range(R) if handles(q, r, R)]
-        send_counts, off = [0] * R, 0
-        for c0 in range(0, len(peers), e.max_peers):              # one launch + one sync per 8 peers
-            chunk = peers[c0:c0 + e.max_peers]
-            lists, stride, counts = e.select_multi(own_rows, m, boxes_host[chunk])
-            for k, q in enumerate(chunk):
-                if off + counts[k] > self.ghost_capacity:
-                    raise RuntimeError("halo of rank %d exceeds its capacity %d" % (r, self.ghost_capacity))
-                e.pack5(own_rows, own_gids, lists, k * stride, counts[k], e.halo5, off)
-                send_counts[q] = counts[k]
-                off += counts[k]
-        recv_counts = x.exchange_counts(send_counts)
+        if len(peers) > e.max_peers:
+            raise NotImplementedError("more than %d halo peers per rank" % e.max_peers)
+        lists, stride, counts = e.select_multi(own_rows, m, boxes, peers)
+        e.pack5_lists(own_rows, own_gids, lists, stride, counts, len(peers), m, e.halo5)
+        per_rank = torch.zeros(R, dtype=counts.dtype, device=counts.device)
+        if peers:
+            per_rank[torch.tensor(peers, device=counts.device)] = counts[:len(peers)]
+        send_counts, recv_counts = x.exchange_counts(per_rank)                     # the step's 2nd host sync
         g = sum(recv_counts)
-        if g > self.ghost_capacity:
-            raise RuntimeError("rank %d would receive %d ghosts > capacity %d" % (r, g, self.ghost_capacity))
+        if sum(send_counts) > self.ghost_capacity or g > self.ghost_capacity:
+            raise RuntimeError("halo of rank %d (%d out, %d in) exceeds its capacity %d"
+                               % (r, sum(send_counts), g, self.ghost_capacity))
         x.all_to_all_v(e.halo5, send_counts, e.ghost5, recv_counts)
         e.unpack5(e.ghost5, g, e.ghost_rows, e.ghost_gids)
         self.stats["ghosts"] = g

@@ -196,10 +196,15 @@ int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii);
 /* 5-word transport records (x, y, z, r, gid): one all-to-all moves a sphere */
 int col_pack5(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec);
 int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii);
-/* halo selection against n_boxes <= 8 peer boxes (HOST array of n_boxes x 8 floats: lo.xyz,-,hi.xyz,-)
- * in one launch: lists[k*stride ...] / counts[k] per box; counts zeroed by the caller */
-int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const float *boxes, int n_boxes,
-                             uint32_t stride, uint32_t *lists, uint32_t *counts);
+/* halo selection in one launch: boxes = DEVICE array [world][8] (lo.xyz,-,hi.xyz,-) as produced by
+ * the AABB all-gather; peers = HOST array of n_peers <= 8 rank numbers; lists[k*stride ...] and
+ * counts[k] (zeroed by the caller) receive the spheres overlapping boxes[peers[k]] */
+int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
+                             int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts);
+/* pack the n_lists lists back to back into transport records; sizes are read on the device */
+int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists,
+                    uint32_t stride, const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec,
+                    uint32_t rec_capacity);
 /* indices of rows whose box strictly overlaps aabb (2 x vec4) appended to out; *count zeroed by caller */
 int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out,
                        uint32_t *count);

@@ -96,14 +96,24 @@ class OracleEngine:
         lo, hi = self._lo.min(axis=0), self._hi.max(axis=0)
         return t.tensor([lo[0], lo[1], lo[2], 0, hi[0], hi[1], hi[2], 0], dtype=t.float32)
 
-    def select_multi(self, rows, n, boxes_host):
-        counts = []
-        for k, b in enumerate(boxes_host):
+    def select_multi(self, rows, n, boxes_dev, peers):
+        t = self.torch
+        counts = t.zeros(self.max_peers, dtype=t.int32)
+        boxes = boxes_dev.numpy()
+        for k, q in enumerate(peers):
+            b = boxes[q]
             hit = ((self._hi > b[0:3]) & (self._lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
             idx = np.nonzero(hit)[0].astype(np.int32)
-            self.sel_lists[k * self.capacity:k * self.capacity + len(idx)] = self.torch.from_numpy(idx)
-            counts.append(len(idx))
+            self.sel_lists[k * self.capacity:k * self.capacity + len(idx)] = t.from_numpy(idx)
+            counts[k] = len(idx)
         return self.sel_lists, self.capacity, counts
+
+    def pack5_lists(self, rows, gids, lists, stride, counts_dev, n_lists, n, out5):
+        off = 0
+        for k in range(n_lists):
+            c = int(counts_dev[k])
+            self.pack5(rows, gids, lists, k * stride, c, out5, off)
+            off += c
 
     def ghost_queries(self, rows, gids, n_ghost, owned_gids):
         if self.n_owned == 0 or n_ghost == 0:
