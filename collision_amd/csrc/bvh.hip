@@ -452,7 +452,8 @@ int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_
 
 size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
     return 256 /* scene range */ + col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4) +
-           col_radix_scratch_bytes(padded, 4, 4) + col_lbvh_scratch_bytes(n, coord_bytes) + 512;
+           col_radix_scratch_bytes(padded, 4, 4) + col_lbvh_scratch_bytes(n, coord_bytes) +
+           (size_t)n * 4 * coord_bytes /* packed (x,y,z,r) rows */ + 1024;
 }
 
 int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
@@ -462,8 +463,10 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
     if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     hipStream_t s = col_stream(stream);
-    COL_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), s));                 // collision.py:151-154
-    if (n == 0) return COL_OK;
+    if (n == 0) {
+        COL_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), s));             // collision.py:151-154
+        return COL_OK;
+    }
     (void)flags;   // the arrival counters of internalBounds (collision.py:147-150) are not needed: see lbvh.hip
     char *p = (char *)scratch;
     void *range = p;           p += 256;
@@ -471,12 +474,14 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     void *sort_scratch = p;    p += col_radix_scratch_bytes(padded, 4, 4);
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    void *lbvh_scratch = p;
+    void *lbvh_scratch = p;    p += col_lbvh_scratch_bytes(n, coord_bytes);
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    void *packed = p;
     int rc;
     if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
-    if ((rc = col_morton(stream, coords, range, n, padded, coord_bytes, codes0, ids0))) return rc;
+    if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;
     if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
-    if ((rc = col_lbvh(stream, codes1, ids1, coords, radii, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
     return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
 }
 

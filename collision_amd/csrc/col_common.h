@@ -19,6 +19,13 @@
         if (e_ != hipSuccess) return (int)e_;          \
     } while (0)
 
+// internal entry points shared between translation units (not part of the public header)
+extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii, const void *range, uint32_t n,
+                             uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
+                             uint32_t *zero_word);
+extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
+                           const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes);
+
 static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }
 
 static inline uint64_t col_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

@@ -202,6 +202,7 @@ struct __attribute__((packed, aligned(4))) InnerTail { u32 right_edge, child_a, 
 template <typename T>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
+                                             const T *__restrict__ packed,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial,
                                              T *__restrict__ tab1, u32 n, int dbg) {
@@ -227,8 +228,15 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (valid) {
         id = ids[p];
         const u32 gid = (dbg & 1) ? p : id;
-        const V4 c = reinterpret_cast<const V4 *>(coords)[gid];
-        const T r = radii[gid];
+        V4 c;
+        T r;
+        if (packed) {                 // (x, y, z, r) rows written by col_morton_ex: one gather per leaf
+            c = reinterpret_cast<const V4 *>(packed)[gid];
+            r = c.w;
+        } else {
+            c = reinterpret_cast<const V4 *>(coords)[gid];
+            r = radii[gid];
+        }
         leaf.lo[0] = c.x - r; leaf.lo[1] = c.y - r; leaf.lo[2] = c.z - r;
         leaf.hi[0] = c.x + r; leaf.hi[1] = c.y + r; leaf.hi[2] = c.z + r;
     }
@@ -389,15 +397,15 @@ Layout layout(uint32_t n, int coord_bytes) {
 }
 
 template <typename T>
-int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, col_node *nodes,
-        T *bounds, char *scratch, u32 n) {
+int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
+        col_node *nodes, T *bounds, char *scratch, u32 n) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
-    k_chunk<T><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, nodes, bounds, other_end, partial,
+    k_chunk<T><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
                                                   (T *)tabs.t[0], n, g_dbg);
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
@@ -420,18 +428,24 @@ void col_debug_lbvh(int mode) { g_dbg = mode; }
 
 size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, coord_bytes).total + 256; }
 
-int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
-             col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
+// `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
+int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
+                const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
     if (n == 0) return COL_OK;
     if (n >= 0x80000000u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
-        return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, nodes,
-                          (float *)bounds, (char *)scratch, n);
+        return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
+                          nodes, (float *)bounds, (char *)scratch, n);
     if (coord_bytes == 8)
-        return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii, nodes,
-                           (double *)bounds, (char *)scratch, n);
+        return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n);
     return COL_EINVAL;
+}
+
+int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
+             col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
+    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes);
 }
 
 }  // extern "C"
