@@ -164,3 +164,44 @@ def test_config2_full_size_properties(hip_env):
     assert count2 == count
     # expected number of AABB contacts for uniform points: n^2/2 * (4r)^3 within a few percent
     assert abs(count - n * n / 2 * (4 * 0.001) ** 3) < 0.1 * count
+
+
+def test_config2_full_size_matches_oracle(oracle, hip_env):
+    """BASELINE config 2 at full size (1 M uniform spheres, r = 0.001, gs = 256), every intermediate
+    bit for bit against the CPU oracle (the C restatement needs < 1 s for this scene)."""
+    coords, radii = uniform_scene(1000000, 0.001, "float32")
+    _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256, ngroups=64)
+    assert 30000 < count < 34000
+
+
+@pytest.mark.parametrize("n", [307200, 307201])
+def test_reference_benchmark_shape_count_only(oracle, hip_env, n):
+    """tests/benchmarks/test_collide.py:24-54: coords U(-1,1)^3, radii U(0.006,0.06), ngroups 8,
+    group_size 128, count-only mode (collisions_buf None, capacity 0)."""
+    ctx, cq = hip_env
+    rng = np.random.RandomState(4)
+    coords = rng.uniform(-1, 1, size=(n, 3)).astype("float32")
+    radii = rng.uniform(0.006, 0.06, size=n).astype("float32")
+    collider = Collider(ctx, n, 8, 128, "float32")
+    count, _ = run_collider(ctx, cq, collider, coords, radii, 0)
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=0, want=False)
+    assert count == ref["count"] and count > n
+
+
+def test_config3_clustered_matches_oracle(oracle, hip_env):
+    """BASELINE config 3 shape at 200 k spheres: dense clusters, ~20 contacts per sphere."""
+    coords, radii = clustered_scene(200000, 0.012, 0.001, "float32")
+    _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256, ngroups=64)
+    assert count > 1000000
+
+
+def test_single_sphere_and_tiny_scenes(oracle, hip_env):
+    ctx, cq = hip_env
+    for n in (1, 2):
+        coords = np.full((n, 3), 0.5, dtype="float32")
+        radii = np.full(n, 0.1, dtype="float32")
+        collider = Collider(ctx, n, 1, 8, "float32")
+        count, pairs = run_collider(ctx, cq, collider, coords, radii, 4)
+        assert count == n * (n - 1) // 2
+        if n == 2:
+            assert pair_set(pairs) == {(0, 1)}
