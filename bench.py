@@ -69,7 +69,7 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
     assert (np.diff(out.astype(np.int64)) >= 0).all()
 
     # the scatter pass alone (pass 0 geometry; offsets prepared once, untimed)
-    tile = call.col_radix_tile(4, 4)
+    tile = call.col_radix_tile(n, 4, 4)
     nblocks = -(-n // tile)
     hist = hip.Buffer(ctx, 256 * nblocks * 4)
     scan_scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nblocks))
@@ -80,9 +80,10 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
 
         def scatter():
             call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, rpass, hist.ptr)
-        scatter()
+        for _ in range(10):                                # warm-up: clocks and caches settle
+            scatter()
         cq.finish()
-        res[name] = time_events(hip, cq, scatter, reps)
+        res[name] = time_events(hip, cq, scatter, 4 * reps)    # average launch duration over 20 launches
 
     def histo():
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)

@@ -51,7 +51,7 @@ _PROTOS = {
     "col_radix_scratch_bytes": (C.c_size_t, [C.c_uint64, C.c_int, C.c_int]),
     "col_radix_sort": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                               C.c_int, C.c_void_p, C.c_int]),
-    "col_radix_tile": (C.c_uint32, [C.c_int, C.c_int]),
+    "col_radix_tile": (C.c_uint32, [C.c_uint64, C.c_int, C.c_int]),
     "col_radix_histogram": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "col_radix_scatter": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                                  C.c_int, C.c_int, C.c_void_p]),

@@ -25,8 +25,12 @@ namespace {
 constexpr int RT = 256;             // threads per block
 constexpr int RW = RT / COL_WAVE;   // 4 waves
 constexpr int RDIG = 256;           // 8-bit digits
-constexpr int IT = 16;              // items per thread
-constexpr int TILE = RT * IT;       // 4096 pairs per block
+// Items per thread, a template parameter of the kernels: 16 (tile = 4096 pairs) when the input is
+// large enough to fill the chip several times over -- longest digit runs, best HBM write pattern --
+// and 4 (tile = 1024) below SMALL_N pairs, where a pass is bound by the latency of one block and
+// more, shorter blocks finish sooner (the 1 M-sphere path).
+constexpr int IT_BIG = 16, IT_SMALL = 4;
+constexpr uint64_t SMALL_N = 4u << 20;
 constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
 
 template <int B> struct Val;
@@ -55,9 +59,10 @@ __device__ __forceinline__ u64 match8(u32 d) {
 }
 
 // ---- histogram: blocks handle `g` consecutive tiles and write g-entry rows per digit ----
-template <typename K>
+template <typename K, int IT>
 __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
                                              int shift, u32 *__restrict__ hist) {
+    constexpr int TILE = RT * IT;
     __shared__ u32 h[HG * RDIG];
     const u32 tid = threadIdx.x;
     for (u32 i = tid; i < g * RDIG; i += RT) h[i] = 0;
@@ -89,11 +94,12 @@ __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_
 }
 
 // ---- scatter ----
-template <typename K, int VB>
+template <typename K, int VB, int IT>
 __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
                                                 const u32 *__restrict__ offsets, int dbg) {
+    constexpr int TILE = RT * IT;
     constexpr bool HAS_V = VB > 0;
     constexpr bool V_LDS = VB == 4 || VB == 8;       // small values are staged through LDS
     typedef typename Val<(VB > 0 ? VB : 4)>::T V;
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 
 int g_radix_dbg = 0;
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, TILE); }
+inline int items_for(uint64_t n) { return n < SMALL_N ? IT_SMALL : IT_BIG; }
+inline u32 tile_for(uint64_t n) { return (u32)(RT * items_for(n)); }
+inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, tile_for(n)); }
 
 inline u32 hist_group(u32 nblocks) {
     // keep >= ~1024 histogram blocks when the input allows, else fewer tiles per block
@@ -323,14 +331,16 @@ inline u32 hist_group(u32 nblocks) {
 template <typename K>
 int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist) {
     const u32 nb = tiles_of(n), g = hist_group(nb);
-    k_hist<K><<<dim3((unsigned)col_ceil_div(nb, g)), dim3(RT), 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    dim3 grid((unsigned)col_ceil_div(nb, g)), block(RT);
+    if (items_for(n) == IT_SMALL) k_hist<K, IT_SMALL><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    else k_hist<K, IT_BIG><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-template <typename K>
-int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
-                   uint64_t n, int vb, int pass, const u32 *offsets) {
+template <typename K, int IT>
+int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                      uint64_t n, int vb, int pass, const u32 *offsets) {
     const u32 nb = tiles_of(n);
     dim3 grid(nb), block(RT);
     const K *ki = (const K *)keys;
@@ -338,15 +348,22 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
     const int shift = pass * 8;
     if (!vals || !vals_out) vb = 0;
     switch (vb) {
-    case 0: k_scatter<K, 0><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
-    case 4: k_scatter<K, 4><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 8: k_scatter<K, 8><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 16: k_scatter<K, 16><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 32: k_scatter<K, 32><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 0: k_scatter<K, 0, IT><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
+    case 4: k_scatter<K, 4, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 8: k_scatter<K, 8, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 16: k_scatter<K, 16, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 32: k_scatter<K, 32, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
     default: return COL_EINVAL;
     }
     COL_LAUNCH_OK();
     return COL_OK;
+}
+
+template <typename K>
+int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                   uint64_t n, int vb, int pass, const u32 *offsets) {
+    return items_for(n) == IT_SMALL ? launch_scatter_it<K, IT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets)
+                                    : launch_scatter_it<K, IT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
 }
 
 inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
@@ -361,7 +378,7 @@ extern "C" {
 
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
-uint32_t col_radix_tile(int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return TILE; }
+uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return tile_for(n); }
 
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
     const size_t nb = tiles_of(n);

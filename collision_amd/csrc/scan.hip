@@ -77,10 +77,10 @@ __global__ __launch_bounds__(ST) void k_scan_apply(u32 *__restrict__ data, uint6
 // Every block publishes its tile sum as an 8-byte {epoch, sum} granule (one relaxed agent-scope
 // atomic store: the data is the flag, cdna_hip_programming.md guideline 16 R2), then wave 0 reads
 // the granules of all predecessor tiles in parallel (lane = predecessor) and adds them up -- a
-// look-back without a chain, so the depth is two hops whatever the tile count.  All <= 64 blocks
-// are resident at once (64 << 256 CUs), so the polls always complete; the epoch makes stale
+// look-back without a chain, so the depth is two hops whatever the tile count.  All <= 256 blocks
+// are resident at once (one per CU at most), so the polls always complete; the epoch makes stale
 // granules from earlier calls invisible without a memset launch.
-constexpr u32 CHAIN_MAX_TILES = 64;
+constexpr u32 CHAIN_MAX_TILES = 256;      // 4 waves x 64 predecessors
 __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n, u64 *__restrict__ status, u32 epoch) {
     __shared__ u32 ws[ST / COL_WAVE];
     __shared__ u32 s_prefix;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n
     u32 run = block_excl_scan<ST>(t, ws, &total);
     if (threadIdx.x == 0)
         __hip_atomic_store(&status[b], ((u64)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < COL_WAVE) {
+    {   // thread t polls predecessor tile t (ST == CHAIN_MAX_TILES); ws is free again after the scan
         u32 pv = 0;
         if (threadIdx.x < b) {
             u64 g;
@@ -105,7 +105,14 @@ __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n
             pv = (u32)g;
         }
         pv = wave_sum(pv);
-        if (threadIdx.x == 0) s_prefix = pv;
+        if (lane_id() == 0) ws[threadIdx.x / COL_WAVE] = pv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 p = 0;
+#pragma unroll
+        for (int i = 0; i < ST / COL_WAVE; i++) p += ws[i];
+        s_prefix = p;
     }
     __syncthreads();
     run += s_prefix;

@@ -31,7 +31,7 @@ def stage_times(hip_mod, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_
     red_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(0 if cb == 4 else 1, 4))
     rng = hip.Buffer(ctx, 256)
     sort_scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(p, 4, 4))
-    tile = call.col_radix_tile(4, 4)
+    tile = call.col_radix_tile(p, 4, 4)
     nb = -(-p // tile)
     hist = hip.Buffer(ctx, 256 * nb * 4)
     scan_scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb))

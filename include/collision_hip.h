@@ -123,7 +123,7 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
                    uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back);
 /* One pass of the production sort, for profiling and per-pass parity:
  * histogram (digit-major, hist[d*nblocks+b]) -> scan -> scatter. */
-uint32_t col_radix_tile(int key_bytes, int val_bytes);         /* elements per block */
+uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes);   /* elements per block for an n-element sort */
 int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_bytes, int val_bytes,
                         int pass, uint32_t *hist);
 int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,

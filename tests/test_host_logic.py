@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.col_version() >= 100
-    assert _lib.call.col_radix_tile(4, 4) % 256 == 0
+    assert _lib.call.col_radix_tile(1 << 26, 4, 4) % 256 == 0 and _lib.call.col_radix_tile(1000, 4, 4) % 256 == 0
     assert lib.col_error_string(-1).decode().startswith("collision_hip")
 
 

@@ -95,7 +95,7 @@ def test_ref_argsort_loop(hip_env, key_dtype, value_dtype, ngroups, group_size):
 def test_production_pass(hip_env, key_dtype, val_bytes, n):
     ctx, cq = hip_env
     kb = np.dtype(key_dtype).itemsize
-    tile = call.col_radix_tile(kb, val_bytes)
+    tile = call.col_radix_tile(n, kb, val_bytes)
     nblocks = -(-n // tile)
     rs = np.random.RandomState(4)
     keys = (rs.randint(0, 2 ** 32, size=n, dtype=np.uint64) * np.uint64(2654435761)).astype(key_dtype)

@@ -143,9 +143,11 @@ def test_sizes_around_the_tile(hip_env):
     """The C ABI takes any n (the 2*group_size rule is the Python class's); ragged tails."""
     from collision_amd._lib import call
     ctx, cq = hip_env
-    tile = call.col_radix_tile(4, 4)
+    tile = call.col_radix_tile(1000, 4, 4)             # small inputs use the small tile ...
+    big = 4 << 20                                      # ... up to this size, then the big one
+    assert call.col_radix_tile(big, 4, 4) > tile
     rs = np.random.RandomState(4)
-    for n in (1, 2, 63, 64, 65, tile - 1, tile, tile + 1, 3 * tile + 17):
+    for n in (1, 2, 63, 64, 65, tile - 1, tile, tile + 1, 3 * tile + 17, big - 1, big, big + 4097):
         keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
         vals = np.arange(n, dtype=np.uint32)
         kb, vb = upload(ctx, keys), upload(ctx, vals)

@@ -10,7 +10,7 @@ rng = np.random.RandomState(4)
 keys = rng.randint(0, 2 ** 30, size=n).astype(np.uint32)
 kin, vin = hip.Buffer(ctx, hostbuf=keys), hip.Buffer(ctx, hostbuf=np.arange(n, dtype=np.uint32))
 kout, vout = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
-tile = call.col_radix_tile(4, 4); nb = -(-n // tile)
+tile = call.col_radix_tile(n, 4, 4); nb = -(-n // tile)
 hist = hip.Buffer(ctx, 256 * nb * 4)
 ss = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb))
 call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
