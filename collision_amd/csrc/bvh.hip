@@ -256,16 +256,51 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             }
             if (packet >= npackets) continue;
             const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
-            // phase 1: candidates inside the packet (x first: cheap reject for the whole wave)
-            for (int p = 1; p <= last && !(mode & 1); p++) {
-                const T plx = readlane_t(lx[k], p), phx = readlane_t(hx[k], p);
-                bool hit = (int)lane < p && hx[k] > plx && lx[k] < phx;
-                if (!__ballot(hit)) continue;
-                const T ply = readlane_t(ly[k], p), plz = readlane_t(lz[k], p);
-                const T phy = readlane_t(hy[k], p), phz = readlane_t(hz[k], p);
-                hit = hit && hy[k] > ply && ly[k] < phy && hz[k] > plz && lz[k] < phz;
-                const u64 hits = __ballot(hit);
-                if (hits) sink.emit(hits, qid[k], (u32)__builtin_amdgcn_readlane((int)qid[k], p));
+            // phase 1: candidates inside the packet.  Exact float tests cost ~30 wave-instructions per
+            // candidate and almost all of them fail, so candidates are first screened with boxes
+            // quantised to 8 bits per axis inside the packet's union box (lo rounded down, hi rounded
+            // up: a real overlap always survives).  The three axes sit in 10-bit fields of one word,
+            // and "a >= b in every field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
+            if (!(mode & 1)) {
+                T ul[3] = {lx[k], ly[k], lz[k]}, uh[3] = {hx[k], hy[k], hz[k]};
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const T l2 = __shfl_xor(ul[a], o, COL_WAVE), h2 = __shfl_xor(uh[a], o, COL_WAVE);
+                        ul[a] = l2 < ul[a] ? l2 : ul[a];
+                        uh[a] = h2 > uh[a] ? h2 : uh[a];
+                    }
+                }
+                const T mylo[3] = {lx[k], ly[k], lz[k]}, myhi[3] = {hx[k], hy[k], hz[k]};
+                u32 qlo = 0, qhi = 0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const T ext = uh[a] - ul[a];
+                    const T sc = ext > (T)0 ? (T)255 / ext : (T)0;
+                    T fl = floor((mylo[a] - ul[a]) * sc), fh = ceil((myhi[a] - ul[a]) * sc);
+                    fl = fl < (T)0 ? (T)0 : (fl > (T)255 ? (T)255 : fl);      // also maps the empty box (inf) to 255 / 0
+                    fh = fh < (T)0 ? (T)0 : (fh > (T)255 ? (T)255 : fh);
+                    if (!(fl == fl)) fl = (T)0;                                  // NaN: stay conservative
+                    if (!(fh == fh)) fh = (T)255;
+                    qlo |= (u32)fl << (10 * a);
+                    qhi |= (u32)fh << (10 * a);
+                }
+                constexpr u32 CARRY = 0x10040100u;
+                const u32 qhi_c = qhi + CARRY;
+                for (int p = 1; p <= last; p++) {
+                    const u32 p_lo = (u32)__builtin_amdgcn_readlane((int)qlo, p);
+                    const u32 p_hi_c = (u32)__builtin_amdgcn_readlane((int)qhi_c, p);
+                    const u32 both = (qhi_c - p_lo) & (p_hi_c - qlo) & CARRY;   // my hi >= its lo, its hi >= my lo
+                    bool hit = (int)lane < p && both == CARRY;
+                    if (!__ballot(hit)) continue;
+                    const T plx = readlane_t(lx[k], p), phx = readlane_t(hx[k], p);
+                    const T ply = readlane_t(ly[k], p), plz = readlane_t(lz[k], p);
+                    const T phy = readlane_t(hy[k], p), phz = readlane_t(hz[k], p);
+                    hit = hit && hx[k] > plx && lx[k] < phx && hy[k] > ply && ly[k] < phy && hz[k] > plz && lz[k] < phz;
+                    const u64 hits = __ballot(hit);
+                    if (hits) sink.emit(hits, qid[k], (u32)__builtin_amdgcn_readlane((int)qid[k], p));
+                }
             }
             idx[k] = (u32)__builtin_amdgcn_readlane((int)qskip, last);
             if (mode & 2) idx[k] = END;
