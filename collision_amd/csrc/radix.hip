@@ -79,7 +79,14 @@ __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_
                 K kk[VEC];
                 *reinterpret_cast<uint4 *>(kk) = *reinterpret_cast<const uint4 *>(keys + i);
 #pragma unroll
-                for (int j = 0; j < VEC; j++) atomicAdd(&ht[digit_of(kk[j], shift)], 1u);
+                for (int j = 0; j < VEC; j++) {
+                    // sorted or low-entropy inputs put one digit in every lane; 64 LDS atomics on one
+                    // address would serialise, so a wave-uniform digit is counted with a single add
+                    const u32 d = digit_of(kk[j], shift);
+                    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+                    if (__ballot(d != d0) == 0) { if (lane_id() == 0) atomicAdd(&ht[d0], (u32)COL_WAVE); }
+                    else atomicAdd(&ht[d], 1u);
+                }
             } else {
                 for (int j = 0; j < VEC; j++)
                     if (i + j < n) atomicAdd(&ht[digit_of(keys[i + j], shift)], 1u);
