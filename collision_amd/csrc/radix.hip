@@ -30,6 +30,7 @@ constexpr int RDIG = 256;           // 8-bit digits
 // and 4 (tile = 1024) below SMALL_N pairs, where a pass is bound by the latency of one block and
 // more, shorter blocks finish sooner (the 1 M-sphere path).
 constexpr int IT_BIG = 16, IT_SMALL = 4;
+constexpr int NT_BIG = 256, NT_SMALL = 256;   // threads per scatter block (512 x 16 measured slower: 0.264 vs 0.240 ms)
 constexpr uint64_t SMALL_N = 4u << 20;
 constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
 
@@ -59,10 +60,10 @@ __device__ __forceinline__ u64 match8(u32 d) {
 }
 
 // ---- histogram: blocks handle `g` consecutive tiles and write g-entry rows per digit ----
-template <typename K, int IT>
+template <typename K, int TILE>
 __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
                                              int shift, u32 *__restrict__ hist) {
-    constexpr int TILE = RT * IT;
+    constexpr int IT = TILE / RT;
     __shared__ u32 h[HG * RDIG];
     const u32 tid = threadIdx.x;
     for (u32 i = tid; i < g * RDIG; i += RT) h[i] = 0;
@@ -101,20 +102,21 @@ __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_
 }
 
 // ---- scatter ----
-template <typename K, int VB, int IT>
-__global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+template <typename K, int VB, int IT, int NT>
+__global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
                                                 const u32 *__restrict__ offsets, int dbg) {
-    constexpr int TILE = RT * IT;
+    constexpr int TILE = NT * IT;
+    constexpr int NW = NT / COL_WAVE;
     constexpr bool HAS_V = VB > 0;
     constexpr bool V_LDS = VB == 4 || VB == 8;       // small values are staged through LDS
     typedef typename Val<(VB > 0 ? VB : 4)>::T V;
     __shared__ K s_keys[TILE];
     __shared__ V s_vals[V_LDS ? TILE : 1];
-    __shared__ u32 s_cnt[RW][RDIG];
+    __shared__ u32 s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
-    __shared__ u32 s_ws[RW];
+    __shared__ u32 s_ws[NW];
 
     const V *vals_in = reinterpret_cast<const V *>(vals_in_);
     V *vals_out = reinterpret_cast<V *>(vals_out_);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
     const uint64_t tile_base = (uint64_t)b * TILE;
     const u32 valid = (u32)min((uint64_t)TILE, n - tile_base);
 
-    for (u32 i = tid; i < RW * RDIG; i += RT) (&s_cnt[0][0])[i] = 0;
+    for (u32 i = tid; i < NW * RDIG; i += NT) (&s_cnt[0][0])[i] = 0;
 
     const u32 wbase = w * (COL_WAVE * IT) + lane;
     K key[IT];
@@ -195,17 +197,22 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
     }
     __syncthreads();
 
-    // digit `tid`: exclusive over waves, then exclusive over digits; fold both into s_cnt
+    // digit `tid` (threads 0..255): exclusive over waves, then exclusive over digits; fold both into s_cnt
     {
-        const u32 c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        u32 c[NW], tot = 0;
+        if (tid < RDIG) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) { c[i] = s_cnt[i][tid]; tot += c[i]; }
+        }
         u32 total;
-        const u32 dstart = block_excl_scan<RT>(c0 + c1 + c2 + c3, s_ws, &total);
-        s_cnt[0][tid] = dstart;
-        s_cnt[1][tid] = dstart + c0;
-        s_cnt[2][tid] = dstart + c0 + c1;
-        s_cnt[3][tid] = dstart + c0 + c1 + c2;
-        // global position of tile-sorted slot i with digit d is s_goff[d] + i
-        s_goff[tid] = offsets[(uint64_t)tid * nblocks + b] - dstart;
+        const u32 dstart = block_excl_scan<NT>(tot, s_ws, &total);      // threads >= 256 contribute 0
+        if (tid < RDIG) {
+            u32 run = dstart;
+#pragma unroll
+            for (int i = 0; i < NW; i++) { s_cnt[i][tid] = run; run += c[i]; }
+            // global position of tile-sorted slot i with digit d is s_goff[d] + i
+            s_goff[tid] = offsets[(uint64_t)tid * nblocks + b] - dstart;
+        }
     }
     __syncthreads();
 
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(RT) void k_scatter(const K *__restrict__ keys_in, K
 
 #pragma unroll
     for (int k = 0; k < IT; k++) {
-        const u32 i = k * RT + tid;
+        const u32 i = k * NT + tid;
         if (i < valid) {
             const K kk = s_keys[i];
             u32 g = s_goff[digit_of(kk, shift)] + i;
@@ -324,8 +331,8 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 
 int g_radix_dbg = 0;
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline int items_for(uint64_t n) { return n < SMALL_N ? IT_SMALL : IT_BIG; }
-inline u32 tile_for(uint64_t n) { return (u32)(RT * items_for(n)); }
+inline bool small_for(uint64_t n) { return n < SMALL_N; }
+inline u32 tile_for(uint64_t n) { return small_for(n) ? (u32)(NT_SMALL * IT_SMALL) : (u32)(NT_BIG * IT_BIG); }
 inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, tile_for(n)); }
 
 inline u32 hist_group(u32 nblocks) {
@@ -339,27 +346,27 @@ template <typename K>
 int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist) {
     const u32 nb = tiles_of(n), g = hist_group(nb);
     dim3 grid((unsigned)col_ceil_div(nb, g)), block(RT);
-    if (items_for(n) == IT_SMALL) k_hist<K, IT_SMALL><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
-    else k_hist<K, IT_BIG><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    if (small_for(n)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    else k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-template <typename K, int IT>
+template <typename K, int IT, int NT>
 int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                       uint64_t n, int vb, int pass, const u32 *offsets) {
     const u32 nb = tiles_of(n);
-    dim3 grid(nb), block(RT);
+    dim3 grid(nb), block(NT);
     const K *ki = (const K *)keys;
     K *ko = (K *)keys_out;
     const int shift = pass * 8;
     if (!vals || !vals_out) vb = 0;
     switch (vb) {
-    case 0: k_scatter<K, 0, IT><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
-    case 4: k_scatter<K, 4, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 8: k_scatter<K, 8, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 16: k_scatter<K, 16, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 32: k_scatter<K, 32, IT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 0: k_scatter<K, 0, IT, NT><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
+    case 4: k_scatter<K, 4, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 8: k_scatter<K, 8, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 16: k_scatter<K, 16, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 32: k_scatter<K, 32, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
     default: return COL_EINVAL;
     }
     COL_LAUNCH_OK();
@@ -369,8 +376,8 @@ int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const voi
 template <typename K>
 int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int vb, int pass, const u32 *offsets) {
-    return items_for(n) == IT_SMALL ? launch_scatter_it<K, IT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets)
-                                    : launch_scatter_it<K, IT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+    return small_for(n) ? launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets)
+                        : launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
 }
 
 inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
