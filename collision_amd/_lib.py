@@ -85,6 +85,7 @@ _PROTOS = {
     "col_traverse_ghost": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_radix": (C.c_int, [C.c_int]),

@@ -24,9 +24,20 @@ static int fill_launch(void *stream, void *dst, const void *pattern, size_t coun
     return COL_OK;
 }
 
+// diagnostics: which XCD (HW_REG_XCC_ID) each workgroup of a 256-thread launch lands on
+__global__ void k_xcc_census(unsigned *out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF;
+}
+
 }  // namespace
 
 extern "C" {
+
+int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks) {
+    k_xcc_census<<<dim3(nblocks), dim3(256), 0, col_stream(stream)>>>(out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
 
 const char *col_error_string(int code) {
     if (code == COL_OK) return "ok";
