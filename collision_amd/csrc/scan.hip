@@ -155,7 +155,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int scan_rec(hipStream_t s, u32 *data, uint64_t n, char *scratch) {
     if (n == 0) return COL_OK;
     const uint64_t nb = col_ceil_div(n, STILE);
-    if (nb > 1 && nb <= CHAIN_MAX_TILES) {
+    // Under stream capture the epoch argument would be frozen into the graph and every replay would
+    // see the previous replay's granules as valid, so a captured scan takes the three-launch path.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (nb > 1 && nb <= CHAIN_MAX_TILES) (void)hipStreamIsCapturing(s, &capture);
+    if (nb > 1 && nb <= CHAIN_MAX_TILES && capture == hipStreamCaptureStatusNone) {
         static u32 epoch = 0x5EED0000u;          // never reused within a process; see k_scan_chain
         epoch++;
         k_scan_chain<<<dim3((unsigned)nb), dim3(ST), 0, s>>>(data, (u32)n, (u64 *)scratch, epoch);

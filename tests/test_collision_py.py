@@ -94,3 +94,43 @@ def test_repeated_calls_and_capacity_overflow(hip_env, coord_dtype, collision_pr
         assert count == len(expected)
         got = pair_set(np.sort(pairs, axis=1))
         assert len(got) == min(cap, len(expected)) and got <= expected
+
+
+def test_get_collisions_survives_graph_capture_and_replay(hip_env, oracle):
+    """The whole path captured once into a hipGraph (torch.cuda.graph on the launch stream) and
+    replayed: every replay must give the eager / oracle pair set.  20 k spheres, so the radix
+    histogram spans several scan tiles (the single-launch scan must step aside under capture)."""
+    torch = pytest.importorskip("torch")
+    ctx, _ = hip_env
+    from collision_amd import hip
+    from tests.util import pad4
+    n, cap = 20000, 1 << 16
+    rng = np.random.RandomState(4)
+    coords = rng.random_sample((n, 3)).astype("float32")
+    radii = np.full(n, 0.008, dtype="float32")
+    ref = oracle.collide(oracle.pad4(coords), radii, capacity=cap)
+    expected = pair_set(ref["pairs"])
+    assert 1000 < ref["count"] < cap
+    c_t = torch.from_numpy(pad4(coords)).cuda()
+    r_t = torch.from_numpy(radii).cuda()
+    n_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p_t = torch.zeros((cap, 2), dtype=torch.int32, device="cuda")
+    collider = Collider(ctx, n, 4, 64, np.dtype("float32"))
+    bufs = [hip.Buffer.from_tensor(ctx, t) for t in (c_t, r_t, n_t, p_t)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        cq = hip.CommandQueue(ctx, stream=side.cuda_stream)
+        collider.get_collisions(cq, bufs[0], bufs[1], bufs[2], bufs[3], cap)      # eager warm-up (allocations)
+        side.synchronize()
+        assert int(n_t.item()) == ref["count"]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            collider.get_collisions(cq, bufs[0], bufs[1], bufs[2], bufs[3], cap)
+        for _ in range(3):
+            p_t.zero_()
+            n_t.fill_(12345)
+            graph.replay()
+            side.synchronize()
+            count = int(n_t.item())
+            assert count == ref["count"]
+            assert pair_set(p_t[:count].cpu().numpy().view(np.uint32)) == expected
