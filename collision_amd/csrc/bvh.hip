@@ -112,42 +112,104 @@ __global__ __launch_bounds__(256) void k_build(const u32 *__restrict__ codes, co
     }
 }
 
-// leafBounds + internalBounds (collision.cl:128-162) in one launch.  The thread that arrives
-// second at a node already holds one child's box in registers and loads only the sibling's.
-// Inter-workgroup hand-off: bounds stores -> agent-scope release fence -> flag atomic;
-// second arriver: flag atomic -> agent-scope acquire fence -> plain loads (per-XCD L2s are
-// not coherent; cdna_hip_programming.md guideline 16).
+// leafBounds + internalBounds (collision.cl:128-162) for ANY binary tree given by parent / children
+// links (the production path uses lbvh.hip, which needs the LBVH's contiguous leaf ranges).
+//
+// The reference's protocol -- every leaf walks up, the second arrival at a node merges -- hands
+// boxes between workgroups through a flag, which on MI355X (8 XCDs, non-coherent L2s) needs an
+// agent-scope release + acquire fence pair per level per wave: 6.3 ms at 1 M leaves.  Here:
+//   k_refit_leaves   leaf boxes.
+//   k_refit_sweep    x R, level-synchronous: a node whose two children were finished by an EARLIER
+//                    launch merges them (visibility comes from the kernel boundary: no fence, no
+//                    atomic).  R = log2(n) + 16 covers LBVHs.  Round r records in the (otherwise
+//                    unused) flag word of leaf r whether it finished anything; if round r-1 did
+//                    not, the tree is complete and round r exits on one scalar load.
+//   k_refit_finish   whatever is still unfinished (trees deeper than R): the reference's walk with
+//                    fences, started from every finished node whose parent is not.
+// Results are identical in every case: min/max are exact.
+constexpr u32 DONE = 0x80000000u;
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_refit(T *__restrict__ bounds, u32 *__restrict__ flags,
-                                                const T *__restrict__ coords, const T *__restrict__ radii,
-                                                const col_node *__restrict__ nodes, u32 n) {
+__global__ __launch_bounds__(256) void k_refit_leaves(T *__restrict__ bounds, u32 *__restrict__ flags,
+                                                       const T *__restrict__ coords, const T *__restrict__ radii,
+                                                       const col_node *__restrict__ nodes, u32 n) {
     typedef typename BTypes<T>::V4 V4;
     typedef typename BTypes<T>::V3 V3;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u32 leaf_start = n - 1;
-    u32 cur = leaf_start + i;
-    const u32 id = nodes[cur].data[0];
+    const u32 node = leaf_start + i;
+    const u32 id = nodes[node].data[0];
     const V4 c = reinterpret_cast<const V4 *>(coords)[id];
     const T r = radii[id];
     V3 mn = {c.x - r, c.y - r, c.z - r};
     V3 mx = {c.x + r, c.y + r, c.z + r};
-    *reinterpret_cast<V3 *>(bounds + 8ull * cur) = mn;
-    *reinterpret_cast<V3 *>(bounds + 8ull * cur + 4) = mx;
-    if (n < 2) return;
+    *reinterpret_cast<V3 *>(bounds + 8ull * node) = mn;
+    *reinterpret_cast<V3 *>(bounds + 8ull * node + 4) = mx;
+}
+
+template <typename T> struct Box3 { T lo[3], hi[3]; };
+template <typename T> __device__ __forceinline__ Box3<T> load_box(const T *bounds, u32 node) {
+    typedef typename BTypes<T>::V4 V4;
+    const V4 a = reinterpret_cast<const V4 *>(bounds)[2ull * node], b = reinterpret_cast<const V4 *>(bounds)[2ull * node + 1];
+    Box3<T> r;
+    r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z; r.hi[0] = b.x; r.hi[1] = b.y; r.hi[2] = b.z;
+    return r;
+}
+template <typename T> __device__ __forceinline__ void merge_store(T *bounds, u32 node, Box3<T> &a, const Box3<T> &b) {
+    typedef typename BTypes<T>::V3 V3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = b.lo[k] < a.lo[k] ? b.lo[k] : a.lo[k];
+        a.hi[k] = b.hi[k] > a.hi[k] ? b.hi[k] : a.hi[k];
+    }
+    V3 mn = {a.lo[0], a.lo[1], a.lo[2]}, mx = {a.hi[0], a.hi[1], a.hi[2]};
+    *reinterpret_cast<V3 *>(bounds + 8ull * node) = mn;        // lane w (traversal links) is preserved
+    *reinterpret_cast<V3 *>(bounds + 8ull * node + 4) = mx;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_refit_sweep(T *__restrict__ bounds, u32 *__restrict__ flags,
+                                                      const col_node *__restrict__ nodes, u32 n, u32 round,
+                                                      u32 *__restrict__ progress) {
+    if (progress && round > 1 && progress[round - 1] == 0) return;     // wave-uniform: the tree is complete
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const u32 leaf_start = n - 1;
+    bool finished = false;
+    if (i < leaf_start && !(flags[i] & DONE)) {
+        const u32 ca = nodes[i].data[0], cb = nodes[i].data[1];
+        // a child counts only if an earlier launch finished it: its box is then visible without a fence
+        const u32 fa = ca >= leaf_start ? DONE : flags[ca], fb = cb >= leaf_start ? DONE : flags[cb];
+        if ((fa & DONE) && (fb & DONE) && (fa & ~DONE) < round && (fb & ~DONE) < round) {
+            Box3<T> box = load_box(bounds, ca);
+            merge_store(bounds, i, box, load_box(bounds, cb));
+            flags[i] = DONE | round;
+            finished = true;
+        }
+    }
+    if (progress && __syncthreads_or(finished) && threadIdx.x == 0) progress[round] = 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_refit_finish(T *__restrict__ bounds, u32 *__restrict__ flags,
+                                                       const col_node *__restrict__ nodes, u32 n,
+                                                       const u32 *__restrict__ last_progress) {
+    if (last_progress && *last_progress == 0) return;       // the last sweep had nothing left to do
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const u32 leaf_start = n - 1;
+    if (i == 0 || i >= 2 * n - 1) return;
+    if (i < leaf_start && !(flags[i] & DONE)) return;       // not finished itself
+    if (flags[nodes[i].parent] & DONE) return;              // parent already finished by a sweep
+    // i is finished, its parent is not: collision.cl:143-162 from here up
+    u32 cur = i;
+    Box3<T> box = load_box(bounds, cur);
     do {
         const u32 parent = nodes[cur].parent;
         __threadfence();
-        if (atomicAdd(&flags[parent], 1u) < 1u) break;   // first arrival: the sibling finishes the node
+        if ((atomicAdd(&flags[parent], 1u) & 3u) < 1u) break;   // first arrival: the sibling finishes the node
         __threadfence();
         const u32 ca = nodes[parent].data[0], cb = nodes[parent].data[1];
-        const u32 sib = ca == cur ? cb : ca;
-        const V4 smn = reinterpret_cast<const V4 *>(bounds)[2ull * sib];
-        const V4 smx = reinterpret_cast<const V4 *>(bounds)[2ull * sib + 1];
-        mn.x = smn.x < mn.x ? smn.x : mn.x; mn.y = smn.y < mn.y ? smn.y : mn.y; mn.z = smn.z < mn.z ? smn.z : mn.z;
-        mx.x = smx.x > mx.x ? smx.x : mx.x; mx.y = smx.y > mx.y ? smx.y : mx.y; mx.z = smx.z > mx.z ? smx.z : mx.z;
-        *reinterpret_cast<V3 *>(bounds + 8ull * parent) = mn;
-        *reinterpret_cast<V3 *>(bounds + 8ull * parent + 4) = mx;
+        merge_store(bounds, parent, box, load_box(bounds, ca == cur ? cb : ca));
         cur = parent;
     } while (cur != 0);
 }
@@ -455,12 +517,27 @@ int col_bvh_build(void *stream, const uint32_t *codes, const uint32_t *ids, col_
 int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coords, const void *radii,
                   const col_node *nodes, uint32_t n, int coord_bytes) {
     if (n == 0) return COL_OK;
-    dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
-    if (coord_bytes == 4)
-        k_refit<float><<<grid, block, 0, col_stream(stream)>>>((float *)bounds, flags, (const float *)coords, (const float *)radii, nodes, n);
-    else if (coord_bytes == 8)
-        k_refit<double><<<grid, block, 0, col_stream(stream)>>>((double *)bounds, flags, (const double *)coords, (const double *)radii, nodes, n);
-    else return COL_EINVAL;
+    if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
+    hipStream_t s = col_stream(stream);
+    dim3 leaves((unsigned)col_ceil_div(n, 256)), inner((unsigned)col_ceil_div(n > 1 ? n - 1 : 1, 256)),
+        all((unsigned)col_ceil_div(2ull * n - 1, 256)), block(256);
+    int rounds = 16;
+    for (uint32_t m = n; m > 1; m >>= 1) rounds++;
+    // progress words live in the flag slots of leaves 1..rounds (never used by the node protocol)
+    uint32_t *progress = (n > (uint32_t)rounds + 1) ? flags + (n - 1) : nullptr;
+    if (coord_bytes == 4) {
+        k_refit_leaves<float><<<leaves, block, 0, s>>>((float *)bounds, flags, (const float *)coords, (const float *)radii, nodes, n);
+        if (n > 1) {
+            for (int r = 1; r <= rounds; r++) k_refit_sweep<float><<<inner, block, 0, s>>>((float *)bounds, flags, nodes, n, (u32)r, progress);
+            k_refit_finish<float><<<all, block, 0, s>>>((float *)bounds, flags, nodes, n, progress ? progress + rounds : nullptr);
+        }
+    } else {
+        k_refit_leaves<double><<<leaves, block, 0, s>>>((double *)bounds, flags, (const double *)coords, (const double *)radii, nodes, n);
+        if (n > 1) {
+            for (int r = 1; r <= rounds; r++) k_refit_sweep<double><<<inner, block, 0, s>>>((double *)bounds, flags, nodes, n, (u32)r, progress);
+            k_refit_finish<double><<<all, block, 0, s>>>((double *)bounds, flags, nodes, n, progress ? progress + rounds : nullptr);
+        }
+    }
     COL_LAUNCH_OK();
     return COL_OK;
 }

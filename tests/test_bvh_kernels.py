@@ -167,3 +167,35 @@ def test_fused_lbvh_equals_generic_kernels_and_oracle(hip_env, oracle, dt, n):
         np.testing.assert_array_equal(na["parent"][1:], ref_nodes["parent"][1:])
         np.testing.assert_array_equal(na["data"][:n - 1], ref_nodes["data"][:n - 1])
         np.testing.assert_array_equal(ba[:, :, :3], ref_bounds[:, :, :3])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [2, 5, 64, 300, 5000])
+def test_refit_on_a_degenerate_chain_tree(hip_env, oracle, dt, n):
+    """col_bvh_refit takes ANY binary tree.  A caterpillar (internal node i = {leaf i, internal i+1})
+    is n-1 levels deep: far beyond the level-synchronous sweeps, so the fence-walk finisher does
+    most of the work.  Compared with the oracle's restatement of leafBounds + internalBounds."""
+    ctx, cq = hip_env
+    rs = np.random.RandomState(n)
+    coords = pad4(rs.uniform(-1, 1, size=(n, 3)).astype(dt))
+    radii = rs.uniform(0.01, 0.1, size=n).astype(dt)
+    leaf = n - 1
+    nodes = np.zeros(2 * n - 1, dtype=Node)
+    nodes["parent"][:] = NO_NODE
+    for i in range(n - 1):
+        right = i + 1 if i + 1 < n - 1 else leaf + n - 1
+        nodes["data"][i] = (leaf + i, right)
+        nodes["right_edge"][i] = n - 1
+        nodes["parent"][leaf + i] = i
+        nodes["parent"][right] = i
+    ids = rs.permutation(n).astype(np.uint32)
+    nodes["data"][leaf:, 0] = ids
+    nodes["right_edge"][leaf:] = np.arange(n)
+    bounds_buf = upload(ctx, np.zeros((2 * n - 1, 2, 4), dt))
+    flags_buf = upload(ctx, np.zeros(2 * n - 1, np.uint32))
+    coords_buf, radii_buf, nodes_buf = upload(ctx, coords), upload(ctx, radii), upload(ctx, nodes)
+    call.col_bvh_refit(cq.stream, bounds_buf.ptr, flags_buf.ptr, coords_buf.ptr, radii_buf.ptr, nodes_buf.ptr, n,
+                       np.dtype(dt).itemsize)
+    got = download(cq, bounds_buf, dt, (2 * n - 1, 2, 4))
+    ref = oracle.node_bounds(coords, radii, nodes)
+    np.testing.assert_array_equal(got[:, :, :3], ref[:, :, :3])
