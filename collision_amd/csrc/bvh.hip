@@ -298,7 +298,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
     const u32 npackets = (n + 63) / 64;
     const u32 nwaves = gridDim.x * TW;
-    u64 trips = 0;
+    u64 trips = 0, descents = 0, leaf_tests = 0, leaf_hits = 0;
 
     for (u32 base = (blockIdx.x * TW + w) * K; base < npackets; base += nwaves * K) {
         T lx[K], ly[K], lz[K], hx[K], hy[K], hz[K];
@@ -391,9 +391,10 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                                      hz[k] > a[k].z && lz[k] < b[k].z;
                 const u64 hits = __ballot(overlap);
                 u32 next = skip;
+                if (stats && idx[k] >= leaf_start) leaf_tests++;
                 if (hits) {
-                    if (idx[k] >= leaf_start) sink.emit(hits, qid[k], down);
-                    else next = down;
+                    if (idx[k] >= leaf_start) { sink.emit(hits, qid[k], down); if (stats) leaf_hits++; }
+                    else { next = down; if (stats) descents++; }
                 }
                 idx[k] = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
@@ -411,12 +412,17 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     __syncthreads();
     sink.copy_out(s_base + s_cnt[w], sink.count);
     if (stats) {                       // diagnostics: phase-2 steps, one atomic per block
-        __shared__ unsigned long long s_trips;
-        if (threadIdx.x == 0) s_trips = 0;
+        __shared__ unsigned long long s_st[4];
+        if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
         __syncthreads();
-        if (lane == 0) atomicAdd(&s_trips, (unsigned long long)trips);
+        if (lane == 0) {
+            atomicAdd(&s_st[0], (unsigned long long)trips);
+            atomicAdd(&s_st[1], (unsigned long long)descents);
+            atomicAdd(&s_st[2], (unsigned long long)leaf_tests);
+            atomicAdd(&s_st[3], (unsigned long long)leaf_hits);
+        }
         __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&stats[0], (u64)s_trips); atomicAdd(&stats[2], 1ull); }
+        if (threadIdx.x < 4) atomicAdd(&stats[threadIdx.x], (u64)s_st[threadIdx.x]);
     }
 }
 
