@@ -43,6 +43,15 @@ template <> struct Val<32> { typedef V32 T; };
 
 template <typename K> __device__ __forceinline__ u32 digit_of(K key, int shift) { return (u32)(key >> shift) & (RDIG - 1); }
 
+// diagnostics (col_debug_radix mode 32): cycles per phase of k_scatter, summed over blocks
+__device__ unsigned long long g_stamp[8];
+#define STAMP(slot)                                                              \
+    if ((dbg & 32) && threadIdx.x == 0) {                                        \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
+        atomicAdd(&g_stamp[slot], t_ - t_prev);                                  \
+        t_prev = t_;                                                             \
+    }
+
 // lanes of this wave whose 8-bit digit equals mine ("match-any").  For every bit the ballot of
 // that bit is XORed with my own bit replicated over the word: the result marks the lanes that
 // DIFFER from me in that bit; the eight results are ORed (v_or3) and complemented.  12 VALU per
@@ -133,6 +142,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     const uint64_t tile_base = (uint64_t)b * TILE;
     const u32 valid = (u32)min((uint64_t)TILE, n - tile_base);
 
+    unsigned long long t_prev = (dbg & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
+    // this tile's global offset of digit `tid`: one scattered 4-byte load per thread, issued now so that
+    // its latency hides under the loads and the ranking instead of sitting between two barriers
+    const u32 my_offset = tid < RDIG ? offsets[(uint64_t)tid * nblocks + b] : 0u;
     for (u32 i = tid; i < NW * RDIG; i += NT) (&s_cnt[0][0])[i] = 0;
 
     const u32 wbase = w * (COL_WAVE * IT) + lane;
@@ -181,6 +194,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         }
     }
     __syncthreads();
+    STAMP(0)      // load + transpose
 
     // rank inside (wave, digit): wave-private counters, program order keeps them consistent
     u32 pos[IT];
@@ -196,6 +210,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         pos[k] = prev + below;
     }
     __syncthreads();
+    STAMP(1)      // ranking
 
     // digit `tid` (threads 0..255): exclusive over waves, then exclusive over digits; fold both into s_cnt
     {
@@ -211,10 +226,11 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 #pragma unroll
             for (int i = 0; i < NW; i++) { s_cnt[i][tid] = run; run += c[i]; }
             // global position of tile-sorted slot i with digit d is s_goff[d] + i
-            s_goff[tid] = offsets[(uint64_t)tid * nblocks + b] - dstart;
+            s_goff[tid] = my_offset - dstart;
         }
     }
     __syncthreads();
+    STAMP(2)      // digit scan + offsets
 
 #pragma unroll
     for (int k = 0; k < IT; k++) {
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         }
     }
     __syncthreads();
+    STAMP(3)      // scatter into LDS
 
 #pragma unroll
     for (int k = 0; k < IT; k++) {
@@ -244,6 +261,8 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
             if (V_LDS) vals_out[g] = s_vals[i];
         }
     }
+    if (dbg & 32) { __builtin_amdgcn_s_waitcnt(0); }
+    STAMP(4)      // read back + global stores (issue only)
 }
 
 // ---- reference-structured kernels (kernel-level parity only; one wave per block) ----
@@ -391,6 +410,13 @@ inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
 extern "C" {
 
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
+
+int col_debug_radix_stamps(uint64_t *out, int reset) {
+    unsigned long long h[8] = {0};
+    if (out) { COL_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h))); for (int i = 0; i < 8; i++) out[i] = h[i]; }
+    if (reset) { unsigned long long z[8] = {0}; COL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z))); }
+    return COL_OK;
+}
 
 uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return tile_for(n); }
 

@@ -32,6 +32,15 @@ for rnd in range(12):                      # interleaved rounds in one process (
 for mode, what in modes:
     t = sorted(times[mode])
     print("mode %d %-26s min %.4f  median %.4f ms  -> %.0f GB/s (median)" % (mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6))
+cdll().col_debug_radix(32)
+call.col_debug_radix_stamps(None, 1)
+run(); cq.finish()
+st = np.zeros(8, np.uint64)
+call.col_debug_radix_stamps(st.ctypes.data, 1)
+tot = float(st[:5].sum())
+print("k_scatter phase shares (thread 0 of every block, s_memtime):",
+      {k: round(float(v) / tot, 3) for k, v in zip(("load+transpose", "rank", "digit scan", "LDS scatter", "readback+stores"), st[:5])},
+      "cycles/block", round(tot / nb))
 cdll().col_debug_radix(0)
 def h():
     call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
