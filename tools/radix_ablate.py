@@ -31,7 +31,7 @@ for rnd in range(12):                      # interleaved rounds in one process (
         times[mode].append(bench.time_events(hip, cq, run, 3))
 for mode, what in modes:
     t = sorted(times[mode])
-    print("mode %d %-26s min %.4f  median %.4f ms  -> %.0f GB/s (median)" % (mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6))
+    print("mode %d %-26s min %.4f  median %.4f ms  -> %.0f GB/s (median)   in order: %s" % (mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6, " ".join("%.3f" % v for v in times[mode])))
 cdll().col_debug_radix(32)
 call.col_debug_radix_stamps(None, 1)
 run(); cq.finish()
