@@ -274,7 +274,7 @@ class HipEngine:
 # --------------------------------------------------------------------------- the protocol
 class DistributedCollider:
     def __init__(self, ctx, dist, n_local, group_size=256, pair_capacity=1 << 19, partition="morton",
-                 slack=1.6, engine=None):
+                 slack=1.6, engine=None, exercise_single_rank=False):
         if partition not in ("morton", "hash"):
             raise ValueError("partition must be 'morton' or 'hash'")
         self.dist, self.partition = dist, partition
@@ -288,6 +288,9 @@ class DistributedCollider:
         self.cq = getattr(self.engine, "cq", None)
         self.n_in = 0
         self.stats = {}
+        # run every exchange even when world_size == 1 (each collective then talks to itself): lets a
+        # one-GPU box drive the real RCCL code paths
+        self.exercise = exercise_single_rank
 
     def set_local_spheres(self, coords4, radii, gids):
         self.n_in = self.engine.load(coords4, radii, gids)
@@ -303,7 +306,7 @@ class DistributedCollider:
         grange = torch.cat([ranges[:, :4].min(dim=0).values, ranges[:, 4:].max(dim=0).values]).contiguous()
 
         # 2. spatial repartition
-        if self.partition == "morton" and R > 1:
+        if self.partition == "morton" and (R > 1 or self.exercise):
             codes, perm = e.sort_by_code(rows, n, grange)
             splitters = self._splitters(codes, n)
             edges = torch.searchsorted(codes[:n].to(torch.int64), splitters)       # codes < 2^30
@@ -322,7 +325,7 @@ class DistributedCollider:
 
         # 3. the single-GPU path on the owned spheres
         e.collide(own_rows, own_gids, m)
-        if R == 1:
+        if R == 1 and not self.exercise:
             return
 
         # 4. region boxes (AABB all-gather #2); they stay on the device
@@ -332,11 +335,11 @@ class DistributedCollider:
         peers = [q for q in range(R) if handles(q, r, R)]
         if len(peers) > e.max_peers:
             raise NotImplementedError("more than %d halo peers per rank" % e.max_peers)
-        lists, stride, counts = e.select_multi(own_rows, m, boxes, peers)
-        e.pack5_lists(own_rows, own_gids, lists, stride, counts, len(peers), m, e.halo5)
-        per_rank = torch.zeros(R, dtype=counts.dtype, device=counts.device)
+        per_rank = torch.zeros(R, dtype=torch.int32, device=boxes.device)
         if peers:
-            per_rank[torch.tensor(peers, device=counts.device)] = counts[:len(peers)]
+            lists, stride, counts = e.select_multi(own_rows, m, boxes, peers)
+            e.pack5_lists(own_rows, own_gids, lists, stride, counts, len(peers), m, e.halo5)
+            per_rank[torch.tensor(peers, device=boxes.device)] = counts[:len(peers)].to(torch.int32)
         send_counts, recv_counts = x.exchange_counts(per_rank)                     # the step's 2nd host sync
         g = sum(recv_counts)
         if sum(send_counts) > self.ghost_capacity or g > self.ghost_capacity:

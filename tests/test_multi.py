@@ -63,3 +63,43 @@ def test_gloo_gpu_rehearsal(tmp_path, world, partition, kind, n):
     assert res["ok"], res
     if partition == "morton" and kind == "uniform":      # a spatial partition keeps the halo thin
         assert max(s["ghosts"] for s in res["stats"]) < 0.6 * n / world
+
+
+@pytest.mark.gpu
+def test_rccl_code_paths_on_one_gpu(tmp_path):
+    """world_size 1 over the nccl (= RCCL) backend with every exchange forced to run: the real
+    all_gather_into_tensor / all_to_all_single / all_reduce calls on device tensors, talking to
+    themselves.  (More ranks need one GPU each: bench.py --gpus N on the 8-GPU node.)"""
+    script = tmp_path / "one_rank.py"
+    script.write_text('''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from collision_amd import hip
+from collision_amd.multi import DistributedCollider
+import oracle
+n = 50000
+rng = np.random.RandomState(4)
+coords = np.zeros((n, 4), np.float32); coords[:, :3] = rng.random_sample((n, 3))
+radii = np.full(n, 0.006, np.float32)
+for partition in ("morton", "hash"):
+    dc = DistributedCollider(hip.Context(0), dist, n, group_size=64, pair_capacity=1 << 20, partition=partition,
+                             exercise_single_rank=True)
+    dc.set_local_spheres(coords, radii, np.arange(n, dtype=np.uint32))
+    for _ in range(2):
+        dc.step()
+    dc.synchronize()
+    cnt, ref = oracle.brute_force(coords, radii)
+    got = set(tuple(sorted(p)) for p in dc.local_pairs().tolist())
+    assert dc.global_pair_count() == cnt == len(got), (partition, dc.global_pair_count(), cnt, len(got))
+    assert got == set(map(tuple, ref.tolist()))
+dist.destroy_process_group()
+print("ok")
+''' % str(ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
