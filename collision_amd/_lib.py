@@ -80,6 +80,7 @@ _PROTOS = {
                                         C.c_uint32, C.c_void_p, C.c_void_p]),
     "col_pack5_lists": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
                                C.c_uint32, C.c_void_p, C.c_uint32]),
+    "col_bucketize_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_select_overlap": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "col_traverse_ghost": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

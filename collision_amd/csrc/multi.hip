@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256) void k_pack5_lists(const float4 *__restrict__ 
     }
 }
 
+// destination rank of a Morton code: number of splitters <= code (splitters sorted, <= 255 of them)
+__global__ __launch_bounds__(256) void k_bucketize(const u32 *__restrict__ codes, u32 n, const u32 *__restrict__ splitters,
+                                                    u32 n_split, u32 *__restrict__ dest) {
+    __shared__ u32 sp[256];
+    if (threadIdx.x < n_split) sp[threadIdx.x] = splitters[threadIdx.x];
+    __syncthreads();
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 c = codes[i];
+    u32 lo = 0, hi = n_split;                // first index with sp[idx] > c
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (sp[mid] <= c) lo = mid + 1; else hi = mid;
+    }
+    dest[i] = lo;
+}
+
 __global__ __launch_bounds__(256) void k_unpack_radii(const float4 *__restrict__ rows, u32 n, float *__restrict__ radii) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) radii[i] = rows[i].w;
@@ -236,6 +253,15 @@ int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const 
     if (gx > 1024) gx = 1024;
     k_pack5_lists<<<dim3(gx, (unsigned)n_lists), dim3(256), 0, col_stream(stream)>>>(
         (const float4 *)rows, gids, lists, stride, counts, (u32 *)rec, rec_capacity);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_bucketize_u32(void *stream, const uint32_t *codes, uint32_t n, const uint32_t *splitters, uint32_t n_split,
+                      uint32_t *dest) {
+    if (n_split > 255) return COL_EINVAL;
+    if (n == 0) return COL_OK;
+    k_bucketize<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, col_stream(stream)>>>(codes, n, splitters, n_split, dest);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -94,8 +94,11 @@ __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_
                     // address would serialise, so a wave-uniform digit is counted with a single add
                     const u32 d = digit_of(kk[j], shift);
                     const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-                    if (__ballot(d != d0) == 0) { if (lane_id() == 0) atomicAdd(&ht[d0], (u32)COL_WAVE); }
-                    else atomicAdd(&ht[d], 1u);
+                    // (only the lanes inside this branch take part: the ragged last tile is partly elsewhere)
+                    const u64 active = __ballot(true);
+                    if (__ballot(d != d0) == 0) {
+                        if (lane_id() == (u32)__builtin_ctzll(active)) atomicAdd(&ht[d0], (u32)__popcll(active));
+                    } else atomicAdd(&ht[d], 1u);
                 }
             } else {
                 for (int j = 0; j < VEC; j++)

@@ -5,9 +5,9 @@ New work -- the reference is single-device.  Spheres arri
 
 1. **AABB all-gather #1** (32 B/rank): min/max of the local centres -> the global scene range, so
    Morton codes mean the same thing on every rank.
-2. **Spatial repartition** (``partition="morton"``, default): Morton code per sphere, local radix
-   sort, R-1 splitters from gathered samples (balanced for clustered scenes too), one
-   variable-size all-to-all of packed rows ``(x, y, z, r)`` + global ids.  Each rank now owns a
+2. **Spatial repartition** (``partition="morton"``, default): Morton code per sphere, R-1
+   splitters from gathered samples (balanced for clustered scenes too), one radix pass that groups
+   the spheres by owner rank, one variable-size all-to-all of 5-word records ``(x, y, z, r, id)``.  Each rank now owns a
    contiguous Morton range, i.e. a compact region.  With ``partition="hash"`` this step is skipped
    and every rank keeps its hash subset (its region is then the whole scene).
 3. **Local path**: exactly the single-GPU pipeline (``col_collide``) on the owned spheres; pair ids
@@ -155,6 +155,10 @@ class HipEngine:
 
         self.rows_in, self.gids_in = rows(capacity), ints(capacity)
         self.codes, self.codes_sorted, self.iota, self.perm = ints(capacity), ints(capacity), ints(capacity), ints(capacity)
+        self.dest = ints(capacity)
+        nb_max = -(-capacity // call.col_radix_tile(1, 4, 4))            # the small tile bounds the block count
+        self.hist = ints(256 * nb_max)
+        self._scan_scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb_max))
         def recs(n):
             return torch.zeros((n, 5), dtype=i32, device=dev)       # transport records (x, y, z, r, gid)
 
@@ -197,12 +201,29 @@ class HipEngine:
             call.col_reduce(self.cq.stream, rows.data_ptr(), n, 0, 4, 0, self._reduce_scratch.ptr, self.range8.data_ptr())
         return self.range8
 
-    def sort_by_code(self, rows, n, range8):
-        s = self.cq.stream
-        call.col_morton(s, rows.data_ptr(), range8.data_ptr(), n, n, 4, self.codes.data_ptr(), self.iota.data_ptr())
-        call.col_radix_sort(s, self.codes.data_ptr(), self.codes_sorted.data_ptr(), self.iota.data_ptr(),
-                            self.perm.data_ptr(), n, 4, 4, self._sort_scratch.ptr, 0)
-        return self.codes_sorted, self.perm
+    def codes_of(self, rows, n, range8):
+        """Morton codes of the rows under the global scene range (unsorted) + the index ramp."""
+        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), n, n, 4, self.codes.data_ptr(),
+                        self.iota.data_ptr())
+        return self.codes
+
+    def group_by_owner(self, codes, n, splitters):
+        """Stable grouping of the local spheres by destination rank: ONE 8-bit radix pass over the
+        owner index (histogram -> scan -> scatter of the production sort) instead of a full sort by
+        code.  Returns (perm, counts) on the device: perm lists the spheres owner by owner."""
+        torch, s = self.torch, self.cq.stream
+        world = int(splitters.numel()) + 1
+        call.col_bucketize_u32(s, codes.data_ptr(), n, splitters.data_ptr(), world - 1, self.dest.data_ptr())
+        nb = -(-max(n, 1) // call.col_radix_tile(max(n, 1), 4, 4))
+        hist = self.hist[:256 * nb]
+        if n == 0:
+            return self.perm, torch.zeros(world, dtype=torch.int32, device=self.device)
+        call.col_radix_histogram(s, self.dest.data_ptr(), n, 4, 4, 0, hist.data_ptr())
+        counts = hist.view(256, nb)[:world].sum(dim=1, dtype=torch.int32)
+        call.col_scan_u32(s, hist.data_ptr(), 256 * nb, self._scan_scratch.ptr)
+        call.col_radix_scatter(s, self.dest.data_ptr(), self.codes_sorted.data_ptr(), self.iota.data_ptr(),
+                               self.perm.data_ptr(), n, 4, 4, 0, hist.data_ptr())
+        return self.perm, counts
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         """out5[out_offset + i] = (rows[idx[idx_offset + i]], gids[...]) for i < n (idx None = identity)."""
@@ -307,12 +328,11 @@ class DistributedCollider:
 
         # 2. spatial repartition
         if self.partition == "morton" and (R > 1 or self.exercise):
-            codes, perm = e.sort_by_code(rows, n, grange)
+            codes = e.codes_of(rows, n, grange)
             splitters = self._splitters(codes, n)
-            edges = torch.searchsorted(codes[:n].to(torch.int64), splitters)       # codes < 2^30
-            edges = torch.cat([edges.new_zeros(1), edges, edges.new_full((1,), n)])
+            perm, counts = e.group_by_owner(codes, n, splitters)
             e.pack5(rows, gids, perm, 0, n, e.send5)
-            send_counts, recv_counts = x.exchange_counts(edges[1:] - edges[:-1])   # the step's 1st host sync
+            send_counts, recv_counts = x.exchange_counts(counts)                   # the step's 1st host sync
             m = sum(recv_counts)
             if m > self.capacity:
                 raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
@@ -352,17 +372,18 @@ class DistributedCollider:
         # 6. ghosts as queries against my tree
         e.ghost_queries(e.ghost_rows, e.ghost_gids, g, own_gids)
 
-    def _splitters(self, sorted_codes, n):
-        """R-1 global quantiles of the Morton codes from SAMPLES evenly spaced local samples."""
+    def _splitters(self, codes, n):
+        """R-1 global quantiles of the Morton codes from SAMPLES strided local samples (the codes are
+        in input order, i.e. id-hash order: a strided sample is a random sample)."""
         torch, R = self.x.torch, self.world
         if n > 0:
-            pos = torch.linspace(0, n - 1, SAMPLES, device=sorted_codes.device).long()
-            sample = sorted_codes[pos].to(torch.int64)
+            pos = torch.linspace(0, n - 1, SAMPLES, device=codes.device).long()
+            sample = codes[pos].to(torch.int64)
         else:
-            sample = torch.full((SAMPLES,), 1 << 30, dtype=torch.int64, device=sorted_codes.device)
+            sample = torch.full((SAMPLES,), 1 << 30, dtype=torch.int64, device=codes.device)
         allsamp = self.x.all_gather(sample).reshape(-1).sort().values
         cut = (torch.arange(1, R, device=allsamp.device) * (allsamp.numel() // R)).long()
-        return allsamp[cut].contiguous()
+        return allsamp[cut].to(torch.int32).contiguous()
 
     # -- results -------------------------------------------------------------------------------
     def synchronize(self):

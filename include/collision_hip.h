@@ -195,6 +195,9 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
 int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids,
                      const uint32_t *idx, uint32_t n, void *rows, uint32_t *out_gids);
 int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii);
+/* dest[i] = number of (sorted, device) splitters <= codes[i]: the owner rank of a Morton code */
+int col_bucketize_u32(void *stream, const uint32_t *codes, uint32_t n, const uint32_t *splitters,
+                      uint32_t n_split, uint32_t *dest);
 /* 5-word transport records (x, y, z, r, gid): one all-to-all moves a sphere */
 int col_pack5(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec);
 int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii);

@@ -57,12 +57,20 @@ class OracleEngine:
             return t.tensor([np.inf] * 4 + [-np.inf] * 4, dtype=t.float32)
         return t.cat([rows[:n].min(dim=0).values, rows[:n].max(dim=0).values])
 
-    def sort_by_code(self, rows, n, range8):
+    def codes_of(self, rows, n, range8):
         codes = self.oracle.morton(rows[:n].numpy(), range8.numpy().reshape(2, 4))
-        perm = np.argsort(codes, kind="stable")
-        self.codes_sorted[:n] = self.torch.from_numpy(codes[perm].view(np.int32))
+        self.codes = self.torch.zeros(self.capacity, dtype=self.torch.int32)
+        self.codes[:n] = self.torch.from_numpy(codes.view(np.int32))
+        return self.codes
+
+    def group_by_owner(self, codes, n, splitters):
+        c = codes[:n].numpy().view(np.uint32)
+        sp = splitters.numpy().view(np.uint32)
+        dest = np.searchsorted(sp, c, side="right")
+        perm = np.argsort(dest, kind="stable")
         self.perm[:n] = self.torch.from_numpy(perm.astype(np.int32))
-        return self.codes_sorted, self.perm
+        counts = np.bincount(dest, minlength=len(sp) + 1).astype(np.int32)
+        return self.perm, self.torch.from_numpy(counts)
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         t = self.torch

@@ -157,3 +157,21 @@ def test_sizes_around_the_tile(hip_env):
         order = np.argsort(keys, kind="stable")
         np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
         np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1000, 4099, 70001, (4 << 20) + 3])
+def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
+    """Keys with one digit per wave (constant, or long constant runs) and a ragged last tile: the
+    histogram's wave-uniform shortcut must count only the lanes that are in range."""
+    from collision_amd._lib import call
+    ctx, cq = hip_env
+    for keys in (np.full(n, 3, np.uint32), (np.arange(n, dtype=np.uint32) // 777) % 5, np.zeros(n, np.uint32)):
+        keys = keys.astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = upload(ctx, keys), upload(ctx, vals)
+        ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+        scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+        call.col_radix_sort(cq.stream, kb.ptr, ko.ptr, vb.ptr, vo.ptr, n, 4, 4, scratch.ptr, 0)
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
+        np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
