@@ -175,3 +175,29 @@ def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
         order = np.argsort(keys, kind="stable")
         np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
         np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("key_dtype,val_bytes", [("uint64", 4), ("uint64", 8), ("uint32", 8), ("uint32", 16),
+                                                 ("uint64", 32), ("uint32", 0), ("uint64", 0)])
+def test_big_tile_all_type_combinations(hip_env, key_dtype, val_bytes):
+    """Above 4 Mi elements the sort uses the 4096-pair tile: every key/value width once."""
+    from collision_amd._lib import call
+    ctx, cq = hip_env
+    n = (4 << 20) + 12345
+    rs = np.random.RandomState(4)
+    kbytes = np.dtype(key_dtype).itemsize
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+    if kbytes == 8:
+        keys = (keys << np.uint64(17)) ^ rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+    keys = keys.astype(key_dtype)
+    keys[::7] = keys[3]                                  # duplicates: stability matters
+    vals = rs.randint(0, 255, size=(n, max(val_bytes, 1))).astype(np.uint8)
+    kb, vb = upload(ctx, keys), upload(ctx, vals)
+    ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+    scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, kbytes, val_bytes))
+    call.col_radix_sort(cq.stream, kb.ptr, ko.ptr, vb.ptr if val_bytes else None, vo.ptr if val_bytes else None, n, kbytes,
+                        val_bytes, scratch.ptr, 0)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(download(cq, ko, key_dtype, n), keys[order])
+    if val_bytes:
+        np.testing.assert_array_equal(download(cq, vo, np.uint8, vals.shape), vals[order])
