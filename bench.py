@@ -207,6 +207,19 @@ def cpu_bruteforce_10k():
     return {"n": 10000, "seconds": dt, "m_spheres_per_s": 10000 / dt / 1e6, "pairs": len(pairs), "cores": 1}
 
 
+def cpu_bruteforce_all_cores(n=100000):
+    """BASELINE.md section 4's "fair many-core figure": the same O(n^2) test tiled over every host core
+    (OpenMP rows of the upper triangle, oracle/collision_oracle.c), with the n^2 extrapolation to 1M."""
+    import oracle
+    c, r = uniform_scene(n)
+    t0 = time.perf_counter()
+    count, threads = oracle.brute_force_count_all_cores(c, r)
+    dt = time.perf_counter() - t0
+    return {"n": n, "seconds": dt, "cores": threads, "pairs": count,
+            "pair_tests_per_s": n * (n - 1) / 2 / dt,
+            "extrapolated_seconds_at_1M": dt * (N_SPHERES / n) ** 2}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,6 +350,7 @@ def main():
         if not args.no_cpu and world == 1:
             cpu = cpu_baseline(coords, radii)
             extra["cpu_bruteforce_config1"] = cpu_bruteforce_10k()
+            extra["cpu_bruteforce_all_cores"] = cpu_bruteforce_all_cores()
         result = {
             "metric": "M spheres/sec end-to-end (bounds->Morton->radix sort->LBVH->refit->traversal)",
             "value": round(value, 2), "unit": "M spheres/s", "n_gpus": world, "steps": args.steps,

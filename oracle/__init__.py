@@ -48,6 +48,7 @@ def lib():
         _lib.orc_collide_f32.restype = C.c_int64
         _lib.orc_collide_f64.restype = C.c_int64
         _lib.orc_round_up.restype = C.c_uint64
+        _lib.orc_brute_force_count_mt_f32.restype = C.c_uint64
     return _lib
 
 
@@ -212,6 +213,15 @@ def brute_force(coords4, radii, capacity=None):
     pairs = np.empty((max(capacity, 1), 2), dtype=np.uint32)
     count = int(fn(_p(pairs), C.c_uint64(capacity), _p(coords4), _p(radii), C.c_uint32(n)))
     return count, pairs[:min(count, capacity)]
+
+
+def brute_force_count_all_cores(coords4, radii):
+    """Pair count of the O(n^2) brute force on every host core (OpenMP) -> (count, threads)."""
+    coords4 = np.ascontiguousarray(coords4, dtype=np.float32)
+    radii = np.ascontiguousarray(radii, dtype=np.float32)
+    nt = C.c_int(0)
+    count = lib().orc_brute_force_count_mt_f32(_p(coords4), _p(radii), C.c_uint32(len(coords4)), C.byref(nt))
+    return int(count), nt.value
 
 
 def collide(coords4, radii, padded=None, capacity=0, want=True):

@@ -104,6 +104,8 @@ def test_random_scenes_vs_reference_find_collisions(oracle, generated, dt, size)
     assert oracle.find_collisions(coords, radii) == expected
     cnt, bf = oracle.brute_force(oracle.pad4(coords), radii)
     assert cnt == len(expected) and set(map(tuple, bf.tolist())) == expected
+    if dt == "float32":  # the all-cores count used by bench.py's many-core CPU figure
+        assert oracle.brute_force_count_all_cores(oracle.pad4(coords), radii)[0] == len(expected)
 
 
 @pytest.mark.parametrize("size,r", [(2000, 0.005), (10000, 0.001)])
