@@ -494,9 +494,14 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     u64 *st = (u64 *)stats;
     // Measured on MI355X, 1 M spheres (tools/trav_ab.py): packet 0.109 ms vs lane-per-query 0.120 ms on
     // the uniform scene, 0.78 vs 1.04 ms on a clustered one (11 M pairs).  Walking K = 2 / 4 packets per
-    // wave in lock step is slower (0.134 / 0.169 ms): the packet walk is bound by instruction issue, not by
-    // the latency of its dependent loads, so only K = 1 is instantiated.
+    // wave in lock step is slower (0.134 / 0.169 ms), so only K = 1 is instantiated.  Halving the resident
+    // waves (variant bit 2: 256 blocks, 4 waves/SIMD) costs +35 % (0.102 -> 0.138 ms), i.e. T ~ 66 us +
+    // 288 us / waves-per-SIMD: about a third of the walk is exposed latency of its dependent record loads
+    // at the hardware's 8 waves/SIMD, the rest is instruction issue.  Vector instead of scalar record
+    // loads (variant bit 1): 0.112 ms.
+    if (g_traverse_variant & 4) g = dim3(blocks > 256 ? 256 : blocks);
     if (g_traverse_variant == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
+    else if (g_traverse_variant & 2) k_traverse<T, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else k_traverse<T, 1, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
     return COL_OK;

@@ -160,7 +160,7 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 /* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
  * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
-void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query */
+void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
