@@ -29,6 +29,8 @@ GROUP_SIZE = 256
 NGROUPS = 64
 PAIR_CAPACITY = 1 << 17
 SORT_KEYS = 1 << 26         # BASELINE config 5
+SORT_WARMUP = 20            # whole sorts before the timed ones
+SCATTER_WARMUP, SCATTER_TIMED = 100, 50     # k_scatter launches: untimed, then the timed region
 
 
 def uniform_scene(n, seed=4):
@@ -61,9 +63,10 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
 
     def whole():
         call.col_radix_sort(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, scratch.ptr, 0)
-    whole()
+    for _ in range(SORT_WARMUP):                               # the uploads idled the GPU: let clocks settle
+        whole()
     cq.finish()
-    sort_ms = time_events(hip, cq, whole, reps)
+    sort_ms = time_events(hip, cq, whole, 2 * reps)
     # sanity: sorted + permutation on a sample
     out = hip.read_buffer(cq, kout, np.uint32, 1 << 20)
     assert (np.diff(out.astype(np.int64)) >= 0).all()
@@ -74,38 +77,32 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
     hist = hip.Buffer(ctx, 256 * nblocks * 4)
     scan_scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nblocks))
     res = {}
-    for name, rpass in (("pass0", 0), ("pass3", 3)):
+    for name, rpass in (("pass3", 3), ("pass0", 0)):
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, rpass, hist.ptr)
         call.col_scan_u32(cq.stream, hist.ptr, 256 * nblocks, scan_scratch.ptr)
 
         def scatter():
             call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, rpass, hist.ptr)
-        for _ in range(10):                                # warm-up: clocks and caches settle
+        cq.finish()
+        time.sleep(0.2)                                        # an idle gap, as between two host-driven phases
+        res[name + "_cold"] = time_events(hip, cq, scatter, 20)        # launches 1-20 after the gap
+        for _ in range(SCATTER_WARMUP):
             scatter()
         cq.finish()
-        res[name] = time_events(hip, cq, scatter, 4 * reps)    # average launch duration over 20 launches
-
-    # the same launch after a long back-to-back series (the launch time is bistable)
-    call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
-    call.col_scan_u32(cq.stream, hist.ptr, 256 * nblocks, scan_scratch.ptr)
-
-    def scatter0():
-        call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
-    for _ in range(100):
-        scatter0()
-    sustained_ms = time_events(hip, cq, scatter0, 20)
+        res[name] = time_events(hip, cq, scatter, SCATTER_TIMED)       # steady state: the timed region
 
     def histo():
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
-    histo()
-    hist_ms = time_events(hip, cq, histo, reps)
+    for _ in range(10):
+        histo()
+    hist_ms = time_events(hip, cq, histo, 4 * reps)
     scatter_ms = res["pass0"]
     algo_bytes = n * 16.0                                  # 2*key + 2*value bytes per pair
     return {
-        "n_keys": n, "sort_ms": sort_ms, "gkeys_per_s": n / sort_ms / 1e6,
+        "n_keys": n, "sort_ms": sort_ms, "gkeys_per_s": n / sort_ms / 1e6, "tile": tile,
         "scatter_ms": scatter_ms, "scatter_ms_top_digit": res["pass3"], "hist_ms": hist_ms,
         "scatter_gbs": algo_bytes / scatter_ms / 1e6,
-        "scatter_ms_sustained": sustained_ms,
+        "scatter_ms_cold": res["pass0_cold"],
         "algo_bytes_per_launch": algo_bytes,
     }
 
@@ -156,9 +153,10 @@ def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
             def run():
                 call.col_radix_sort(cq.stream, kin.ptr, kout.ptr, vin.ptr if with_values else None,
                                     vout.ptr if with_values else None, n, 4, 4 if with_values else 0, scratch.ptr, 0)
-            run()
+            for _ in range(SORT_WARMUP):
+                run()
             cq.finish()
-            ms = time_events(hip, cq, run, reps)
+            ms = time_events(hip, cq, run, 2 * reps)
             out["%s_%s" % (name, "pairs" if with_values else "keys")] = round(n / ms / 1e6, 2)
         del kin
     return out
@@ -173,7 +171,11 @@ def pmc_traffic():
     f = ROOT / "profiles" / "r01_radix64M_pmc.json"
     if not f.exists():
         return None
-    d = json.loads(f.read_text()).get("k_scatter<unsigned int, 4>")
+    summary = json.loads(f.read_text())
+    # the 64 Mi-pair instance: k_scatter<u32 key, 4-byte value, 16 items/thread, 512 threads>
+    names = [k for k in summary if k.startswith("k_scatter<unsigned int, 4")]
+    names.sort(key=lambda k: ("16, 512" not in k, k))
+    d = summary[names[0]] if names else None
     if not d or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
         return None
     return (2.0 * d["FETCH_SIZE"]["median"] + d["WRITE_SIZE"]["median"]) * 1024.0
@@ -338,12 +340,14 @@ def main():
                                    "gkeys_per_s": round(rb["gkeys_per_s"], 3), "sort_ms": round(rb["sort_ms"], 4),
                                    "hist_ms": round(rb["hist_ms"], 4),
                                    "scatter_ms_top_digit": round(rb["scatter_ms_top_digit"], 4)}
-            roofline = {"bound": "hbm", "kernel": "radix k_scatter<u32,4> (64Mi pairs, 8-bit digit, pass 0)",
+            roofline = {"bound": "hbm", "kernel": "radix k_scatter<u32 key, 4-byte value, 16 items, 512 threads> "
+                                                   "(64Mi pairs, 8-bit digit, pass 0, tile %d)" % rb["tile"],
                         "achieved": round(rb["scatter_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(rb["scatter_gbs"] / HBM_PEAK_GBS, 4),
                         "algo_bytes_per_launch": rb["algo_bytes_per_launch"],
                         "launch_ms": round(rb["scatter_ms"], 4),
-                        "launch_ms_after_100_back_to_back": round(rb["scatter_ms_sustained"], 4),
+                        "launches_timed": SCATTER_TIMED, "warmup_launches": SCATTER_WARMUP,
+                        "launch_ms_first_20_after_idle": round(rb["scatter_ms_cold"], 4),
                         "traffic": pmc_traffic(),
                         "traffic_source": "profiles/r01_radix64M_pmc.json (rocprofv3 --pmc, offline pass)"}
         if world == 1:

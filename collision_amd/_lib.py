@@ -91,6 +91,7 @@ _PROTOS = {
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_radix": (C.c_int, [C.c_int]),
     "col_debug_radix_stamps": (None, [C.c_void_p, C.c_int]),
+    "col_debug_radix_tile": (None, [C.c_int]),
     "col_gather": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "col_scatter": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "col_find_offsets": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),

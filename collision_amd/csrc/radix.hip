@@ -23,15 +23,16 @@
 namespace {
 
 constexpr int RT = 256;             // threads per block
-constexpr int RW = RT / COL_WAVE;   // 4 waves
 constexpr int RDIG = 256;           // 8-bit digits
-// Items per thread, a template parameter of the kernels: 16 (tile = 4096 pairs) when the input is
-// large enough to fill the chip several times over -- longest digit runs, best HBM write pattern --
-// and 4 (tile = 1024) below SMALL_N pairs, where a pass is bound by the latency of one block and
-// more, shorter blocks finish sooner (the 1 M-sphere path).
+// Tile classes (threads x items per thread), template parameters of the kernels:
+//   SMALL 256 x 4  = 1024 pairs  below SMALL_N pairs: a pass is bound by the latency of one block, and
+//                                more, shorter blocks finish sooner (the 1 M-sphere path);
+//   MID   256 x 16 = 4096 pairs  up to BIG_N pairs, and for 8-byte keys (LDS);
+//   BIG   512 x 16 = 8192 pairs  above: the digit runs of a tile are ~128 bytes, a full L2 line, so the
+//                                stores no longer depend on the runs of neighbouring tiles meeting in L2.
 constexpr int IT_BIG = 16, IT_SMALL = 4;
-constexpr int NT_BIG = 256, NT_SMALL = 256;   // threads per scatter block (512 x 16 measured slower: 0.264 vs 0.240 ms)
-constexpr uint64_t SMALL_N = 4u << 20;
+constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256;
+constexpr uint64_t SMALL_N = 1u << 20, BIG_N = 16u << 20;   // tools/radix_tile_sweep.py
 constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
 
 template <int B> struct Val;
@@ -113,6 +114,13 @@ __global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_
     for (u32 t = 0; t < cnt; t++) row[t] = h[t * RDIG + tid];
 }
 
+// ablation helper (col_debug_radix modes 128 / 256)
+template <int SCOPE, typename X> __device__ __forceinline__ void st_scope(X *p, X v) {
+    if constexpr (sizeof(X) == 4) __hip_atomic_store(reinterpret_cast<u32 *>(p), *reinterpret_cast<u32 *>(&v), __ATOMIC_RELAXED, SCOPE);
+    else if constexpr (sizeof(X) == 8) __hip_atomic_store(reinterpret_cast<u64 *>(p), *reinterpret_cast<u64 *>(&v), __ATOMIC_RELAXED, SCOPE);
+    else *p = v;
+}
+
 // ---- scatter ----
 template <typename K, int VB, int IT, int NT>
 __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     constexpr bool HAS_V = VB > 0;
     constexpr bool V_LDS = VB == 4 || VB == 8;       // small values are staged through LDS
     typedef typename Val<(VB > 0 ? VB : 4)>::T V;
-    __shared__ K s_keys[TILE];
-    __shared__ V s_vals[V_LDS ? TILE : 1];
+    __shared__ __attribute__((aligned(16))) K s_keys[TILE];
+    __shared__ __attribute__((aligned(16))) V s_vals[V_LDS ? TILE : 1];
     __shared__ u32 s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
     __shared__ u32 s_ws[NW];
@@ -159,25 +167,54 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         // Full tile: 16-byte global loads (lane l takes KV consecutive keys), transposed to the
         // lane-striped order the ranking needs through this wave's own slice of the LDS staging
         // area.  LDS operations of one wave execute in order, so no barrier is needed.
+        // All global loads of the tile (keys AND values) are issued before the first wait: one memory
+        // round trip per tile instead of two.
         K *stage = s_keys + w * (COL_WAVE * IT);
         const K *src = keys_in + tile_base + w * (COL_WAVE * IT);
+        constexpr int VV = 16 / sizeof(V);
+        V *vstage = s_vals + w * (COL_WAVE * IT);
+        const V *vsrc = vals_in + tile_base + w * (COL_WAVE * IT);
+        // The loads are asm statements: hipcc sinks a plain second group of loads below the first
+        // group's LDS writes (to save registers), which serialises two round trips.  hipcc does not
+        // count asm loads, so every destination passes through an explicit vmcnt(0) statement before
+        // its first use (cdna_hip_programming.md 5.7, form ii).
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        v4u kq[IT / KV], vq[V_LDS ? IT / VV : 1];
+        if (dbg & 64) {                          // timing ablation: non-temporal (streaming) loads
 #pragma unroll
-        for (int j = 0; j < IT / KV; j++) {
-            const u32 o = j * (COL_WAVE * KV) + lane * KV;
-            *reinterpret_cast<uint4 *>(stage + o) = *reinterpret_cast<const uint4 *>(src + o);
+            for (int j = 0; j < IT / KV; j++)
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(kq[j]) : "v"(src + j * (COL_WAVE * KV) + lane * KV) : "memory");
+            if (V_LDS) {
+#pragma unroll
+                for (int j = 0; j < IT / VV; j++)
+                    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(vq[j]) : "v"(vsrc + j * (COL_WAVE * VV) + lane * VV) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < IT / KV; j++)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kq[j]) : "v"(src + j * (COL_WAVE * KV) + lane * KV) : "memory");
+            if (V_LDS) {
+#pragma unroll
+                for (int j = 0; j < IT / VV; j++)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vq[j]) : "v"(vsrc + j * (COL_WAVE * VV) + lane * VV) : "memory");
+            }
         }
+#pragma unroll
+        for (int j = 0; j < IT / KV; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(kq[j])::"memory");
+        if (V_LDS) {
+#pragma unroll
+            for (int j = 0; j < IT / VV; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq[j])::"memory");
+        }
+#pragma unroll
+        for (int j = 0; j < IT / KV; j++)
+            *reinterpret_cast<v4u *>(stage + j * (COL_WAVE * KV) + lane * KV) = kq[j];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < IT; k++) key[k] = stage[k * COL_WAVE + lane];
         if (V_LDS) {
-            constexpr int VV = 16 / sizeof(V);
-            V *vstage = s_vals + w * (COL_WAVE * IT);
-            const V *vsrc = vals_in + tile_base + w * (COL_WAVE * IT);
 #pragma unroll
-            for (int j = 0; j < IT / VV; j++) {
-                const u32 o = j * (COL_WAVE * VV) + lane * VV;
-                *reinterpret_cast<uint4 *>(vstage + o) = *reinterpret_cast<const uint4 *>(vsrc + o);
-            }
+            for (int j = 0; j < IT / VV; j++)
+                *reinterpret_cast<v4u *>(vstage + j * (COL_WAVE * VV) + lane * VV) = vq[j];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < IT; k++) val[k] = vstage[k * COL_WAVE + lane];
@@ -254,16 +291,26 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     STAMP(3)      // scatter into LDS
 
 #pragma unroll
-    for (int k = 0; k < IT; k++) {
-        const u32 i = k * NT + tid;
-        if (i < valid) {
-            const K kk = s_keys[i];
-            u32 g = s_goff[digit_of(kk, shift)] + i;
-            if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
-            keys_out[g] = kk;
-            if (V_LDS) vals_out[g] = s_vals[i];
+        for (int k = 0; k < IT; k++) {
+            const u32 i = k * NT + tid;
+            if (i < valid) {
+                const K kk = s_keys[i];
+                u32 g = s_goff[digit_of(kk, shift)] + i;
+                if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
+                if (dbg & 384) {            // timing ablations: stores at system (128) / agent (256) scope
+                    if (dbg & 128) {
+                        st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&keys_out[g], kk);
+                        if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&vals_out[g], s_vals[i]);
+                    } else {
+                        st_scope<__HIP_MEMORY_SCOPE_AGENT>(&keys_out[g], kk);
+                        if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_AGENT>(&vals_out[g], s_vals[i]);
+                    }
+                } else {
+                    keys_out[g] = kk;
+                    if (V_LDS) vals_out[g] = s_vals[i];
+                }
+            }
         }
-    }
     if (dbg & 32) { __builtin_amdgcn_s_waitcnt(0); }
     STAMP(4)      // read back + global stores (issue only)
 }
@@ -353,9 +400,14 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 
 int g_radix_dbg = 0;
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline bool small_for(uint64_t n) { return n < SMALL_N; }
-inline u32 tile_for(uint64_t n) { return small_for(n) ? (u32)(NT_SMALL * IT_SMALL) : (u32)(NT_BIG * IT_BIG); }
-inline u32 tiles_of(uint64_t n) { return (u32)col_ceil_div(n, tile_for(n)); }
+int g_radix_tile_override = 0;      // diagnostics (col_debug_radix_tile): 0 = automatic, else 1024 / 4096 / 8192
+inline u32 tile_for(uint64_t n, int key_bytes) {
+    u32 t = n < SMALL_N ? (u32)(NT_SMALL * IT_SMALL) : n < BIG_N ? (u32)(NT_MID * IT_BIG) : (u32)(NT_BIG * IT_BIG);
+    if (g_radix_tile_override) t = (u32)g_radix_tile_override;
+    if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
+    return t;
+}
+inline u32 tiles_of(uint64_t n, int key_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes)); }
 
 inline u32 hist_group(u32 nblocks) {
     // keep >= ~1024 histogram blocks when the input allows, else fewer tiles per block
@@ -366,10 +418,13 @@ inline u32 hist_group(u32 nblocks) {
 
 template <typename K>
 int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist) {
-    const u32 nb = tiles_of(n), g = hist_group(nb);
+    const u32 tile = tile_for(n, (int)sizeof(K));
+    const u32 nb = tiles_of(n, (int)sizeof(K)), g = hist_group(nb);
     dim3 grid((unsigned)col_ceil_div(nb, g)), block(RT);
-    if (small_for(n)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
-    else k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>((const K *)keys, n, nb, g, pass * 8, hist);
+    const K *k = (const K *)keys;
+    if (tile == (u32)(NT_SMALL * IT_SMALL)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
+    else if (tile == (u32)(NT_MID * IT_BIG)) k_hist<K, NT_MID * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
+    else k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -377,18 +432,20 @@ int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist
 template <typename K, int IT, int NT>
 int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                       uint64_t n, int vb, int pass, const u32 *offsets) {
-    const u32 nb = tiles_of(n);
+    const u32 nb = tiles_of(n, (int)sizeof(K));
     dim3 grid(nb), block(NT);
     const K *ki = (const K *)keys;
     K *ko = (K *)keys_out;
     const int shift = pass * 8;
     if (!vals || !vals_out) vb = 0;
+    // timing ablation: unused dynamic LDS lowers the number of resident blocks per CU (modes 512 / 1024)
+    const size_t dyn = (g_radix_dbg & 1024) ? 18432 : (g_radix_dbg & 512) ? 4608 : 0;
     switch (vb) {
-    case 0: k_scatter<K, 0, IT, NT><<<grid, block, 0, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
-    case 4: k_scatter<K, 4, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 8: k_scatter<K, 8, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 16: k_scatter<K, 16, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 32: k_scatter<K, 32, IT, NT><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 0: k_scatter<K, 0, IT, NT><<<grid, block, dyn, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
+    case 4: k_scatter<K, 4, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 8: k_scatter<K, 8, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 16: k_scatter<K, 16, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 32: k_scatter<K, 32, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
     default: return COL_EINVAL;
     }
     COL_LAUNCH_OK();
@@ -398,8 +455,14 @@ int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const voi
 template <typename K>
 int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int vb, int pass, const u32 *offsets) {
-    return small_for(n) ? launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets)
-                        : launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+    const u32 tile = tile_for(n, (int)sizeof(K));
+    if (tile == (u32)(NT_SMALL * IT_SMALL))
+        return launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+    if (tile == (u32)(NT_MID * IT_BIG))
+        return launch_scatter_it<K, IT_BIG, NT_MID>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+    if constexpr (sizeof(K) == 4)
+        return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+    return COL_EINVAL;
 }
 
 inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
@@ -414,6 +477,12 @@ extern "C" {
 
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
+int col_debug_radix_tile(int tile) {
+    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG) return COL_EINVAL;
+    g_radix_tile_override = tile;
+    return COL_OK;
+}
+
 int col_debug_radix_stamps(uint64_t *out, int reset) {
     unsigned long long h[8] = {0};
     if (out) { COL_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h))); for (int i = 0; i < 8; i++) out[i] = h[i]; }
@@ -421,10 +490,10 @@ int col_debug_radix_stamps(uint64_t *out, int reset) {
     return COL_OK;
 }
 
-uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)key_bytes; (void)val_bytes; return tile_for(n); }
+uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)val_bytes; return tile_for(n, key_bytes); }
 
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
-    const size_t nb = tiles_of(n);
+    const size_t nb = tiles_of(n, key_bytes);
     const size_t hist = align256((size_t)RDIG * (nb ? nb : 1) * sizeof(u32));
     return hist + align256(col_scan_scratch_bytes((uint64_t)RDIG * nb)) + align256((size_t)n * key_bytes) +
            align256((size_t)n * val_bytes) + 256;
@@ -454,7 +523,7 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
     if (n == 0) return COL_OK;
     if (!scratch) return COL_ENOSCRATCH;
     hipStream_t s = col_stream(stream);
-    const size_t nb = tiles_of(n);
+    const size_t nb = tiles_of(n, key_bytes);
     char *p = (char *)scratch;
     u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));

@@ -162,7 +162,10 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
 void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
-void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps */
+void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
+                                           64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU */
+int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192; 0 = automatic).  Set it BEFORE sizing
+                                           scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it. */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                        const void *bounds, uint32_t n, int coord_bytes, uint64_t *stats, int mode);

@@ -92,7 +92,18 @@ def test_ref_argsort_loop(hip_env, key_dtype, value_dtype, ngroups, group_size):
 @pytest.mark.parametrize("key_dtype,val_bytes", [("uint32", 0), ("uint32", 4), ("uint32", 8), ("uint64", 4),
                                                  ("uint64", 16), ("uint32", 32)])
 @pytest.mark.parametrize("n", [5000, 70001])
-def test_production_pass(hip_env, key_dtype, val_bytes, n):
+@pytest.mark.parametrize("force_tile", [0, 4096, 8192])
+def test_production_pass(hip_env, key_dtype, val_bytes, n, force_tile):
+    """One histogram + scatter pass at a time against NumPy; force_tile runs the 4096- and
+    8192-pair kernels (normally chosen from 1 Mi / 16 Mi elements) on the same small inputs."""
+    call.col_debug_radix_tile(force_tile)
+    try:
+        _production_pass(hip_env, key_dtype, val_bytes, n)
+    finally:
+        call.col_debug_radix_tile(0)
+
+
+def _production_pass(hip_env, key_dtype, val_bytes, n):
     ctx, cq = hip_env
     kb = np.dtype(key_dtype).itemsize
     tile = call.col_radix_tile(n, kb, val_bytes)

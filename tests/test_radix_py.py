@@ -144,10 +144,13 @@ def test_sizes_around_the_tile(hip_env):
     from collision_amd._lib import call
     ctx, cq = hip_env
     tile = call.col_radix_tile(1000, 4, 4)             # small inputs use the small tile ...
-    big = 4 << 20                                      # ... up to this size, then the big one
-    assert call.col_radix_tile(big, 4, 4) > tile
+    mid, big = 1 << 20, 16 << 20                       # ... then 4096 pairs from here, 8192 from there
+    assert tile < call.col_radix_tile(mid, 4, 4) < call.col_radix_tile(big, 4, 4)
+    assert call.col_radix_tile(mid - 1, 4, 4) == tile and call.col_radix_tile(big - 1, 4, 4) == call.col_radix_tile(mid, 4, 4)
+    assert call.col_radix_tile(big, 8, 4) == call.col_radix_tile(mid, 4, 4)      # 8-byte keys stop at the middle tile
     rs = np.random.RandomState(4)
-    for n in (1, 2, 63, 64, 65, tile - 1, tile, tile + 1, 3 * tile + 17, big - 1, big, big + 4097):
+    for n in (1, 2, 63, 64, 65, tile - 1, tile, tile + 1, 3 * tile + 17, mid - 1, mid, mid + 4097, big - 1, big,
+              big + 8193):
         keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
         vals = np.arange(n, dtype=np.uint32)
         kb, vb = upload(ctx, keys), upload(ctx, vals)
@@ -159,7 +162,7 @@ def test_sizes_around_the_tile(hip_env):
         np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
 
 
-@pytest.mark.parametrize("n", [1000, 4099, 70001, (4 << 20) + 3])
+@pytest.mark.parametrize("n", [1000, 4099, 70001, (1 << 20) + 3, (16 << 20) + 3])
 def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
     """Keys with one digit per wave (constant, or long constant runs) and a ragged last tile: the
     histogram's wave-uniform shortcut must count only the lanes that are in range."""
@@ -179,11 +182,12 @@ def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
 
 @pytest.mark.parametrize("key_dtype,val_bytes", [("uint64", 4), ("uint64", 8), ("uint32", 8), ("uint32", 16),
                                                  ("uint64", 32), ("uint32", 0), ("uint64", 0)])
-def test_big_tile_all_type_combinations(hip_env, key_dtype, val_bytes):
-    """Above 4 Mi elements the sort uses the 4096-pair tile: every key/value width once."""
+@pytest.mark.parametrize("n", [(1 << 20) + 12345, (16 << 20) + 12345])
+def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
+    """From 1 Mi elements the sort uses the 4096-pair tile, from 16 Mi the 8192-pair one (4-byte
+    keys): every key/value width once in each."""
     from collision_amd._lib import call
     ctx, cq = hip_env
-    n = (4 << 20) + 12345
     rs = np.random.RandomState(4)
     kbytes = np.dtype(key_dtype).itemsize
     keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
@@ -191,7 +195,7 @@ def test_big_tile_all_type_combinations(hip_env, key_dtype, val_bytes):
         keys = (keys << np.uint64(17)) ^ rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
     keys = keys.astype(key_dtype)
     keys[::7] = keys[3]                                  # duplicates: stability matters
-    vals = rs.randint(0, 255, size=(n, max(val_bytes, 1))).astype(np.uint8)
+    vals = rs.randint(0, 255, size=(n, max(val_bytes, 1)), dtype=np.uint8)
     kb, vb = upload(ctx, keys), upload(ctx, vals)
     ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
     scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, kbytes, val_bytes))
