@@ -291,26 +291,26 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     STAMP(3)      // scatter into LDS
 
 #pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const u32 i = k * NT + tid;
-            if (i < valid) {
-                const K kk = s_keys[i];
-                u32 g = s_goff[digit_of(kk, shift)] + i;
-                if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
-                if (dbg & 384) {            // timing ablations: stores at system (128) / agent (256) scope
-                    if (dbg & 128) {
-                        st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&keys_out[g], kk);
-                        if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&vals_out[g], s_vals[i]);
-                    } else {
-                        st_scope<__HIP_MEMORY_SCOPE_AGENT>(&keys_out[g], kk);
-                        if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_AGENT>(&vals_out[g], s_vals[i]);
-                    }
+    for (int k = 0; k < IT; k++) {
+        const u32 i = k * NT + tid;
+        if (i < valid) {
+            const K kk = s_keys[i];
+            u32 g = s_goff[digit_of(kk, shift)] + i;
+            if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
+            if (dbg & 384) {                           // timing ablations: stores at system (128) / agent (256) scope
+                if (dbg & 128) {
+                    st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&keys_out[g], kk);
+                    if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&vals_out[g], s_vals[i]);
                 } else {
-                    keys_out[g] = kk;
-                    if (V_LDS) vals_out[g] = s_vals[i];
+                    st_scope<__HIP_MEMORY_SCOPE_AGENT>(&keys_out[g], kk);
+                    if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_AGENT>(&vals_out[g], s_vals[i]);
                 }
+            } else {
+                keys_out[g] = kk;
+                if (V_LDS) vals_out[g] = s_vals[i];
             }
         }
+    }
     if (dbg & 32) { __builtin_amdgcn_s_waitcnt(0); }
     STAMP(4)      // read back + global stores (issue only)
 }
