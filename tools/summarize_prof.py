@@ -35,18 +35,20 @@ def stats_rows_from_db(path):
         per[r["name"]].append(float(r["duration"]))
     total = sum(sum(v) for v in per.values())
     rows = [{"Name": k, "Calls": len(v), "AverageNs": sum(v) / len(v), "MinNs": min(v), "MaxNs": max(v),
-             "Percentage": 100.0 * sum(v) / total, "_total": sum(v)} for k, v in per.items()]
+             "MedianNs": sorted(v)[len(v) // 2], "Percentage": 100.0 * sum(v) / total, "_total": sum(v)}
+            for k, v in per.items()]
     rows.sort(key=lambda r: -r["_total"])
     return rows
 
 
 def stats(path):
     rows = stats_rows_from_db(path) if path.endswith(".db") else list(csv.DictReader(open(path)))
-    print("%-44s %7s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+    print("%-44s %7s %12s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "median_us", "min_us", "max_us", "pct"))
     for r in rows:
-        print("%-44s %7s %12.2f %12.2f %12.2f %7.2f" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
-                                                       float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
-                                                       float(r["Percentage"])))
+        med = "%12.2f" % (float(r["MedianNs"]) / 1e3) if "MedianNs" in r else "%12s" % "-"
+        print("%-44s %7s %12.2f %s %12.2f %12.2f %7.2f" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, med,
+                                                          float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                          float(r["Percentage"])))
 
 
 def pmc(paths):
