@@ -20,8 +20,8 @@ def copy():
 copy(); cq.finish()
 ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
-modes = ((0, "full"), (2, "rank + coalesced write"), (64, "non-temporal loads"), (512, "+4.5 KB LDS per block"),
-         (1024, "+18 KB LDS per block (1 block/CU at the 8192 tile)"))
+modes = ((0, "full"), (2, "rank + coalesced write"), (4, "blockIdx tile order (no XCD remap)"), (64, "non-temporal loads"),
+         (512, "+4.5 KB LDS per block"), (1024, "+18 KB LDS per block (1 block/CU at the 8192 tile)"))
 times = {m: [] for m, _ in modes}
 def run():
     call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
