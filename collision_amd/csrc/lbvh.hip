@@ -341,9 +341,13 @@ __global__ __launch_bounds__(C) void k_group(T *__restrict__ tab, u32 count, T *
 
 struct Tabs { void *t[3]; };
 
+// `lin`: the table level whose sparse table was not built because it has at most LIN entries (one
+// launch less on inputs up to 2 M leaves); a range on that level is a short scan of its level-0 row.
+constexpr u32 LIN = 32;
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
-                                               const T *__restrict__ partial, Tabs tabs, u32 n) {
+                                               const T *__restrict__ partial, Tabs tabs, u32 n, int lin) {
     typedef typename BT<T>::V4 V4;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i + 1 >= n) return;
@@ -356,6 +360,10 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
     a += 1; b -= 1;                      // whole chunks strictly between the two ends
     for (int h = 0; h < 3 && a <= b; h++) {
         const T *tab = (const T *)tabs.t[h];
+        if (h == lin) {                  // single group, level 0 only: entry e sits at index e
+            for (int64_t e = a; e <= b; e++) box_merge(box, box_load(tab, (uint64_t)e));
+            break;
+        }
         const int64_t ga = a / C, gb = b / C;
         if (ga == gb) {
             box_merge(box, gtab_query(tab, (uint64_t)ga, (int)(a % C), (int)(b % C)));
@@ -409,13 +417,15 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
                                                   (T *)tabs.t[0], n, g_dbg);
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
+    int lin = -1;
     for (int h = 0; h < 3; h++) {
+        if (h > 0 && L.count[h] <= LIN) { lin = h; break; }      // k_cross scans this level's few entries itself
         const u32 groups = (u32)col_ceil_div(L.count[h], C);
         k_group<T><<<dim3(groups), dim3(C), 0, s>>>((T *)tabs.t[h], L.count[h], h + 1 < 3 ? (T *)tabs.t[h + 1] : nullptr);
         COL_LAUNCH_OK();
         if (groups < 2) break;
     }
-    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n);
+    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n, lin);
     COL_LAUNCH_OK();
     return COL_OK;
 }
