@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void k_refit_finish(T *__restrict__ bounds, u3
 // cache lines per wave-instruction and a wave runs as long as its slowest lane (measured: 12
 // visits per query but 34 trips per wave, 4 us per trip).  Here the CANDIDATE is wave-uniform and
 // the 64 queries are tested against it in parallel:
-//   phase 1  candidates = the wave's own leaves 1..63, read from registers with v_readlane;
-//            lane q tests candidate p > q.
+//   phase 1  pairs inside the packet: lane q meets lane (q + r) mod 64 for r = 1..32 (wave
+//            shuffles), every unordered pair once.
 //   phase 2  candidates beyond the wave: the skip-chain that starts after the wave's LAST leaf is
 //            the same for all 64 queries, so one uniform walk serves them all: one 32-byte
 //            record per step at a wave-uniform address, descend iff ANY lane's box overlaps.
@@ -281,9 +281,9 @@ struct PairSink {
     __device__ __forceinline__ void emit_each(u64 hits, u32 qid, u32 pid) { emit(hits, qid, pid); }
 };
 
-// K packets per wave are walked together in phase 2 so that K dependent record loads are in
-// flight per wave instead of one (the walk is latency bound: one 32-byte record per step).
-template <typename T, int K, bool VEC>
+// STATS: count phase-2 steps for col_traverse_stats (diagnostics); the production instance carries
+// no counters.  VEC: record loads as vector loads at a uniform address (ablation).
+template <typename T, bool STATS, bool VEC>
 __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode) {
@@ -300,104 +300,93 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const u32 nwaves = gridDim.x * TW;
     u64 trips = 0, descents = 0, leaf_tests = 0, leaf_hits = 0;
 
-    for (u32 base = (blockIdx.x * TW + w) * K; base < npackets; base += nwaves * K) {
-        T lx[K], ly[K], lz[K], hx[K], hy[K], hz[K];
-        u32 qid[K], idx[K];
+    for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += nwaves) {
+        const u32 q0 = packet * 64, q = q0 + lane;
+        T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;      // empty box: overlaps nothing
+        u32 qid = 0, qskip = END;
+        if (q < n) {
+            const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
+            lx = a.x; ly = a.y; lz = a.z; hx = b.x; hy = b.y; hz = b.z;
+            qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+            qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
+        }
+        const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
+        // phase 1: pairs inside the packet.  Exact float tests cost ~30 wave-instructions per pair
+        // and almost all of them fail, so pairs are first screened with boxes quantised to 8 bits
+        // per axis inside the packet's union box (lo rounded down, hi rounded up: a real overlap
+        // always survives).  The three axes sit in 10-bit fields of one word, and "a >= b in every
+        // field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
+        if (!(mode & 1)) {
+            T ul[3] = {lx, ly, lz}, uh[3] = {hx, hy, hz};
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const u32 packet = base + k;
-            const u32 q0 = packet * 64, q = q0 + lane;
-            lx[k] = (T)INFINITY; ly[k] = lx[k]; lz[k] = lx[k]; hx[k] = -lx[k]; hy[k] = -lx[k]; hz[k] = -lx[k];   // empty
-            qid[k] = 0; idx[k] = END;
-            u32 qskip = END;
-            if (packet < npackets && q < n) {
-                const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
-                lx[k] = a.x; ly[k] = a.y; lz[k] = a.z; hx[k] = b.x; hy[k] = b.y; hz[k] = b.z;
-                qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
-                qid[k] = (u32) * reinterpret_cast<const Bits *>(&b.w);
-            }
-            if (packet >= npackets) continue;
-            const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
-            // phase 1: candidates inside the packet.  Exact float tests cost ~30 wave-instructions per
-            // candidate and almost all of them fail, so candidates are first screened with boxes
-            // quantised to 8 bits per axis inside the packet's union box (lo rounded down, hi rounded
-            // up: a real overlap always survives).  The three axes sit in 10-bit fields of one word,
-            // and "a >= b in every field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
-            if (!(mode & 1)) {
-                T ul[3] = {lx[k], ly[k], lz[k]}, uh[3] = {hx[k], hy[k], hz[k]};
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        const T l2 = __shfl_xor(ul[a], o, COL_WAVE), h2 = __shfl_xor(uh[a], o, COL_WAVE);
-                        ul[a] = l2 < ul[a] ? l2 : ul[a];
-                        uh[a] = h2 > uh[a] ? h2 : uh[a];
-                    }
-                }
-                const T mylo[3] = {lx[k], ly[k], lz[k]}, myhi[3] = {hx[k], hy[k], hz[k]};
-                u32 qlo = 0, qhi = 0;
+            for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    const T ext = uh[a] - ul[a];
-                    const T sc = ext > (T)0 ? (T)255 / ext : (T)0;
-                    T fl = floor((mylo[a] - ul[a]) * sc), fh = ceil((myhi[a] - ul[a]) * sc);
-                    fl = fl < (T)0 ? (T)0 : (fl > (T)255 ? (T)255 : fl);      // also maps the empty box (inf) to 255 / 0
-                    fh = fh < (T)0 ? (T)0 : (fh > (T)255 ? (T)255 : fh);
-                    if (!(fl == fl)) fl = (T)0;                                  // NaN: stay conservative
-                    if (!(fh == fh)) fh = (T)255;
-                    qlo |= (u32)fl << (10 * a);
-                    qhi |= (u32)fh << (10 * a);
-                }
-                constexpr u32 CARRY = 0x10040100u;
-                const u32 qhi_c = qhi + CARRY;
-                for (int p = 1; p <= last; p++) {
-                    const u32 p_lo = (u32)__builtin_amdgcn_readlane((int)qlo, p);
-                    const u32 p_hi_c = (u32)__builtin_amdgcn_readlane((int)qhi_c, p);
-                    const u32 both = (qhi_c - p_lo) & (p_hi_c - qlo) & CARRY;   // my hi >= its lo, its hi >= my lo
-                    bool hit = (int)lane < p && both == CARRY;
-                    if (!__ballot(hit)) continue;
-                    const T plx = readlane_t(lx[k], p), phx = readlane_t(hx[k], p);
-                    const T ply = readlane_t(ly[k], p), plz = readlane_t(lz[k], p);
-                    const T phy = readlane_t(hy[k], p), phz = readlane_t(hz[k], p);
-                    hit = hit && hx[k] > plx && lx[k] < phx && hy[k] > ply && ly[k] < phy && hz[k] > plz && lz[k] < phz;
-                    const u64 hits = __ballot(hit);
-                    if (hits) sink.emit(hits, qid[k], (u32)__builtin_amdgcn_readlane((int)qid[k], p));
+                    const T l2 = __shfl_xor(ul[a], o, COL_WAVE), h2 = __shfl_xor(uh[a], o, COL_WAVE);
+                    ul[a] = l2 < ul[a] ? l2 : ul[a];
+                    uh[a] = h2 > uh[a] ? h2 : uh[a];
                 }
             }
-            idx[k] = (u32)__builtin_amdgcn_readlane((int)qskip, last);
-            if (mode & 2) idx[k] = END;
+            const T mylo[3] = {lx, ly, lz}, myhi[3] = {hx, hy, hz};
+            u32 qlo = 0, qhi = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const T ext = uh[a] - ul[a];
+                const T sc = ext > (T)0 ? (T)255 / ext : (T)0;
+                T fl = floor((mylo[a] - ul[a]) * sc), fh = ceil((myhi[a] - ul[a]) * sc);
+                fl = fl < (T)0 ? (T)0 : (fl > (T)255 ? (T)255 : fl);      // also maps the empty box (inf) to 255 / 0
+                fh = fh < (T)0 ? (T)0 : (fh > (T)255 ? (T)255 : fh);
+                if (!(fl == fl)) fl = (T)0;                                  // NaN: stay conservative
+                if (!(fh == fh)) fh = (T)255;
+                qlo |= (u32)fl << (10 * a);
+                qhi |= (u32)fh << (10 * a);
+            }
+            constexpr u32 CARRY = 0x10040100u;
+            const u32 qhi_c = qhi + CARRY;
+            // Rotation schedule: lane q meets lane (q + r) mod 64 for r = 1..32, i.e. every unordered
+            // pair of the packet exactly once (r = 32 pairs the two halves: only the lower half tests).
+            // 32 rounds of two wave shuffles; broadcasting candidates 1..63 with v_readlane instead
+            // takes 63 rounds in which half the lanes are idle (measured 0.107 vs 0.097 ms, 1 M spheres).
+            for (int r = 1; r <= 32; r++) {
+                const int pl = (int)((lane + r) & 63u);
+                const u32 p_lo = (u32)__shfl((int)qlo, pl, COL_WAVE);
+                const u32 p_hi_c = (u32)__shfl((int)qhi_c, pl, COL_WAVE);
+                const u32 both = (qhi_c - p_lo) & (p_hi_c - qlo) & CARRY;   // my hi >= its lo, its hi >= my lo
+                bool hit = both == CARRY && (r < 32 || lane < 32u);
+                if (!__builtin_amdgcn_ballot_w64(hit)) continue;
+                const T plx = __shfl(lx, pl, COL_WAVE), phx = __shfl(hx, pl, COL_WAVE);
+                const T ply = __shfl(ly, pl, COL_WAVE), phy = __shfl(hy, pl, COL_WAVE);
+                const T plz = __shfl(lz, pl, COL_WAVE), phz = __shfl(hz, pl, COL_WAVE);
+                const u32 pid = (u32)__shfl((int)qid, pl, COL_WAVE);
+                hit = hit && hx > plx && lx < phx && hy > ply && ly < phy && hz > plz && lz < phz;
+                const u64 hits = __builtin_amdgcn_ballot_w64(hit);
+                const bool mine_first = (int)lane < pl;                  // the earlier sorted leaf comes first
+                if (hits) sink.emit(hits, mine_first ? qid : pid, mine_first ? pid : qid);
+            }
         }
 
-        // phase 2: everything after each packet's last leaf; K uniform walks in lock step
-        for (;;) {
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < K; k++) any |= idx[k] != END;
-            if (!any) break;
-            V4 a[K], b[K];
-#pragma unroll
-            for (int k = 0; k < K; k++) {                      // issue all K record loads first
-                u32 li = idx[k] != END ? idx[k] : 0u;           // finished walks re-read the root (harmless)
-                if (VEC) asm volatile("" : "+v"(li));           // vector load at a uniform address
-                a[k] = rows[2ull * li]; b[k] = rows[2ull * li + 1];
+        // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain
+        u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
+        if (mode & 2) idx = END;
+        while (idx != END) {
+            u32 li = idx;
+            if (VEC) asm volatile("" : "+v"(li));               // vector load at a uniform address
+            const V4 a = rows[2ull * li], b = rows[2ull * li + 1];
+            const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+            const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
+            // Six lane masks ANDed as scalars: a '&&' chain makes hipcc fetch the record piecemeal behind
+            // branches, and the ballot of a combined bool costs a v_cndmask + v_cmp round trip.
+            const u64 hits = __builtin_amdgcn_ballot_w64(hx > a.x) & __builtin_amdgcn_ballot_w64(lx < b.x) &
+                             __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
+                             __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
+            const bool is_leaf = idx >= leaf_start;
+            if (STATS) { trips++; leaf_tests += is_leaf; }
+            u32 next = skip;
+            if (hits) {
+                if (is_leaf) { sink.emit(hits, qid, down); if (STATS) leaf_hits++; }
+                else { next = down; if (STATS) descents++; }
             }
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (idx[k] == END) continue;
-                trips++;
-                const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a[k].w);
-                const u32 down = (u32) * reinterpret_cast<const Bits *>(&b[k].w);
-                const bool overlap = hx[k] > a[k].x && lx[k] < b[k].x && hy[k] > a[k].y && ly[k] < b[k].y &&
-                                     hz[k] > a[k].z && lz[k] < b[k].z;
-                const u64 hits = __ballot(overlap);
-                u32 next = skip;
-                if (stats && idx[k] >= leaf_start) leaf_tests++;
-                if (hits) {
-                    if (idx[k] >= leaf_start) { sink.emit(hits, qid[k], down); if (stats) leaf_hits++; }
-                    else { next = down; if (stats) descents++; }
-                }
-                idx[k] = (u32)__builtin_amdgcn_readfirstlane((int)next);
-            }
+            idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
         }
     }
 
@@ -411,7 +400,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     }
     __syncthreads();
     sink.copy_out(s_base + s_cnt[w], sink.count);
-    if (stats) {                       // diagnostics: phase-2 steps, one atomic per block
+    if (STATS) {                       // diagnostics: phase-2 steps, one atomic per block
         __shared__ unsigned long long s_st[4];
         if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
         __syncthreads();
@@ -492,17 +481,18 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     hipStream_t s = col_stream(stream);
     const T *bd = (const T *)bounds;
     u64 *st = (u64 *)stats;
-    // Measured on MI355X, 1 M spheres (tools/trav_ab.py): packet 0.109 ms vs lane-per-query 0.120 ms on
+    // Measured on MI355X, 1 M spheres (tools/trav_ab.py): packet walk vs lane-per-query 0.109 vs 0.120 ms on
     // the uniform scene, 0.78 vs 1.04 ms on a clustered one (11 M pairs).  Walking K = 2 / 4 packets per
-    // wave in lock step is slower (0.134 / 0.169 ms), so only K = 1 is instantiated.  Halving the resident
-    // waves (variant bit 2: 256 blocks, 4 waves/SIMD) costs +35 % (0.102 -> 0.138 ms), i.e. T ~ 66 us +
-    // 288 us / waves-per-SIMD: about a third of the walk is exposed latency of its dependent record loads
-    // at the hardware's 8 waves/SIMD, the rest is instruction issue.  Vector instead of scalar record
-    // loads (variant bit 1): 0.112 ms.
+    // wave in lock step was slower (0.134 / 0.169 ms) and is gone.  Halving the resident waves (variant
+    // bit 2: 256 blocks, 4 waves/SIMD) costs +35 % (0.102 -> 0.138 ms), i.e. T ~ 66 us + 288 us /
+    // waves-per-SIMD: about a third of the walk is exposed latency of its dependent record loads at the
+    // hardware's 8 waves/SIMD, the rest is instruction issue.  Vector instead of scalar record loads
+    // (variant bit 1): 0.112 ms.
     if (g_traverse_variant & 4) g = dim3(blocks > 256 ? 256 : blocks);
     if (g_traverse_variant == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
-    else if (g_traverse_variant & 2) k_traverse<T, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else k_traverse<T, 1, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (st) k_traverse<T, true, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (g_traverse_variant & 2) k_traverse<T, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else k_traverse<T, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }
