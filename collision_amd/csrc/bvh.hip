@@ -591,9 +591,19 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     void *packed = p;
     int rc;
-    if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
-    if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;
-    if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
+    if (col_radix_tile(padded, 4, 4) == 1024) {
+        // small inputs are launch-bound: the Morton kernel folds the bounds partials itself and counts
+        // the sort's pass-0 digits (the histogram sits at the start of the sort scratch): two launches less
+        uint32_t parts = 0;
+        if ((rc = col_minmax4_stage1(stream, coords, n, coord_bytes, red_scratch, &parts))) return rc;
+        if ((rc = col_morton_tile(stream, coords, radii, red_scratch, parts, n, padded, coord_bytes, codes0, ids0, packed,
+                                  counter, (uint32_t *)sort_scratch, (uint32_t)col_ceil_div(padded, 1024)))) return rc;
+        if ((rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1))) return rc;
+    } else {
+        if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
+        if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;
+        if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
+    }
     if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
     return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
 }

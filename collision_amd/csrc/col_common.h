@@ -26,6 +26,22 @@ extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes);
 
+// col_collide's fused front end for inputs sorted with the 1024-pair tile (fewer launches, same bits):
+//  * col_minmax4_stage1: stage 1 of col_reduce(MINMAX, width 4) only; `parts` partial results of
+//    [min row, max row] are left in `partials` (at most COL_MINMAX_PARTS of them);
+//  * col_morton_tile: col_morton_ex that folds those partials itself (no stage-2 launch) and also
+//    writes the pass-0 histogram of the radix sort, tile = 1024 codes per block, digit-major
+//    hist[d * nblocks + b] like k_hist;
+//  * col_radix_sort_ex(have_hist0 = 1): col_radix_sort that finds the pass-0 histogram already at the
+//    start of `scratch`.
+#define COL_MINMAX_PARTS 256
+extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
+extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
+                               uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
+                               uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks);
+extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                                 uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
+
 static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }
 
 static inline uint64_t col_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

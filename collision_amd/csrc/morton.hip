@@ -61,9 +61,111 @@ __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coor
     if (ids) ids[i] = i;      // collision.cl:8-10
 }
 
+// The same codes, for col_collide's small-input path: one block per 1024-code tile of the radix sort.
+// The block folds the `parts` partial [min row, max row] results of the bounds reduction itself
+// (min/max are exact and order-independent, so every block gets the bits of a stage-2 launch), and
+// counts its tile's pass-0 digits in LDS while the codes are in registers.
+constexpr int MT_TILE = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__ coords, const T *__restrict__ partials,
+                                                      u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
+                                                      u32 *__restrict__ ids, const T *__restrict__ radii,
+                                                      Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
+                                                      u32 *__restrict__ hist0, u32 nblocks) {
+    __shared__ T s_fold[4][8];
+    __shared__ u32 s_hist[256];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0 && zero_word) *zero_word = 0;
+    s_hist[tid] = 0;
+    T acc[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[k] = (T)INFINITY; acc[4 + k] = -(T)INFINITY; }
+    for (u32 i = tid; i < parts; i += 256) {
+        const T *q = partials + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[k] = q[k] < acc[k] ? q[k] : acc[k];
+            acc[4 + k] = q[4 + k] > acc[4 + k] ? q[4 + k] : acc[4 + k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const T lo = __shfl_xor(acc[k], o, 64), hi = __shfl_xor(acc[4 + k], o, 64);
+            acc[k] = lo < acc[k] ? lo : acc[k];
+            acc[4 + k] = hi > acc[4 + k] ? hi : acc[4 + k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_fold[w][k] = acc[k];
+    }
+    __syncthreads();
+    Vec4<T> mn, mx;
+    {
+        T r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = s_fold[0][k];
+#pragma unroll
+        for (int ww = 1; ww < 4; ww++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[k] = s_fold[ww][k] < r[k] ? s_fold[ww][k] : r[k];
+                r[4 + k] = s_fold[ww][4 + k] > r[4 + k] ? s_fold[ww][4 + k] : r[4 + k];
+            }
+        }
+        mn.x = r[0]; mn.y = r[1]; mn.z = r[2]; mn.w = r[3];
+        mx.x = r[4]; mx.y = r[5]; mx.z = r[6]; mx.w = r[7];
+    }
+#pragma unroll
+    for (int k = 0; k < MT_TILE / 256; k++) {
+        const u32 i = blockIdx.x * MT_TILE + k * 256 + tid;
+        if (i >= padded) continue;
+        u32 code = 0xFFFFFFFFu;   // collision.py:137-142
+        if (i < n) {
+            const Vec4<T> c = coords[i];
+            if (packed) {
+                Vec4<T> pr = c;
+                pr.w = radii[i];
+                packed[i] = pr;
+            }
+            code = (expand_bits(quantize(c.x, mn.x, mx.x)) << 2) + (expand_bits(quantize(c.y, mn.y, mx.y)) << 1) +
+                   expand_bits(quantize(c.z, mn.z, mx.z));
+        }
+        codes[i] = code;
+        if (ids) ids[i] = i;
+        atomicAdd(&s_hist[code & 255u], 1u);
+    }
+    __syncthreads();
+    hist0[(uint64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
+}
+
 }  // namespace
 
 extern "C" {
+
+int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
+                    uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
+                    uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks) {
+    if (padded < n || parts == 0 || !hist0) return COL_EINVAL;
+    if (padded == 0) return COL_OK;
+    if (packed && !radii) return COL_EINVAL;
+    if (nblocks != (uint32_t)col_ceil_div(padded, MT_TILE)) return COL_EINVAL;
+    dim3 grid(nblocks), block(256);
+    if (coord_bytes == 4)
+        k_morton_tile<float><<<grid, block, 0, col_stream(stream)>>>((const Vec4<float> *)coords, (const float *)partials, parts,
+                                                                     n, padded, codes, ids, (const float *)radii,
+                                                                     (Vec4<float> *)packed, zero_word, hist0, nblocks);
+    else if (coord_bytes == 8)
+        k_morton_tile<double><<<grid, block, 0, col_stream(stream)>>>((const Vec4<double> *)coords, (const double *)partials,
+                                                                      parts, n, padded, codes, ids, (const double *)radii,
+                                                                      (Vec4<double> *)packed, zero_word, hist0, nblocks);
+    else
+        return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
 
 // col_morton plus two by-products for col_collide: packed (x, y, z, r) rows and a zeroed word.
 int col_morton_ex(void *stream, const void *coords, const void *radii, const void *range, uint32_t n, uint32_t padded,

@@ -518,6 +518,11 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
 
 int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back) {
+    return col_radix_sort_ex(stream, keys, keys_out, vals, vals_out, n, key_bytes, val_bytes, scratch, copy_back, 0);
+}
+
+int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                      uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0) {
     if (!vals || !vals_out) val_bytes = 0;
     if (bad_sizes(n, key_bytes, val_bytes)) return COL_EINVAL;
     if (n == 0) return COL_OK;
@@ -534,7 +539,7 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
     for (int pass = 0; pass < passes; pass++) {
         void *dst_k = (pass & 1) ? keys_out : tmp_keys;
         void *dst_v = (pass & 1) ? vals_out : tmp_vals;
-        int rc = col_radix_histogram(stream, src_k, n, key_bytes, val_bytes, pass, hist);
+        int rc = (pass == 0 && have_hist0) ? COL_OK : col_radix_histogram(stream, src_k, n, key_bytes, val_bytes, pass, hist);
         if (rc) return rc;
         rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);
         if (rc) return rc;

@@ -151,6 +151,23 @@ int by_op(void *stream, const void *values, uint64_t n, int width, int op, void 
 
 extern "C" {
 
+int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts) {
+    uint64_t blocks = col_ceil_div(n, (uint64_t)RT * 16);
+    if (blocks > COL_MINMAX_PARTS) blocks = COL_MINMAX_PARTS;
+    if (blocks == 0) blocks = 1;
+    *parts = (uint32_t)blocks;
+    if (coord_bytes == 4)
+        k_reduce1<float, 4, COL_OP_MINMAX><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>(
+            (const Row<float, 4> *)rows, n, (float *)partials);
+    else if (coord_bytes == 8)
+        k_reduce1<double, 4, COL_OP_MINMAX><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>(
+            (const Row<double, 4> *)rows, n, (double *)partials);
+    else
+        return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
 size_t col_reduce_scratch_bytes(int dtype, int width) {
     size_t eb = (dtype == COL_F32 || dtype == COL_U32 || dtype == COL_I32) ? 4 : 8;
     return (size_t)RMAX_BLOCKS * 2 * (size_t)width * eb;
