@@ -297,10 +297,21 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
     const u32 npackets = (n + 63) / 64;
-    const u32 nwaves = gridDim.x * TW;
-    u64 trips = 0, descents = 0, leaf_tests = 0, leaf_hits = 0;
+    u64 trips = 0, descents = 0, leaf_tests = 0, leaf_hits = 0, win[4] = {0, 0, 0, 0};
 
-    for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += nwaves) {
+    // XCD-aware order: blockIdx % 8 is the XCD, each with its own L2.  Neighbouring packets walk nearly
+    // the same nodes, so every XCD takes one contiguous eighth of the packet groups (16 packets = one
+    // block's worth) and its blocks stride through it; the records a block misses in the scalar cache
+    // are then mostly in its XCD's L2 already.  (Speed only; mode bit 3 restores the plain order.)
+    const u32 ngroups = (npackets + TW - 1) / TW;
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = (gridDim.x + 7u - xcd) >> 3;
+    const u32 g_lo = (u32)(((u64)ngroups * xcd) >> 3), g_hi = (u32)(((u64)ngroups * (xcd + 1)) >> 3);
+    const bool plain = (mode & 8) || gridDim.x < 8;
+    u32 group = plain ? blockIdx.x : g_lo + slot;
+    const u32 g_end = plain ? ngroups : g_hi, g_step = plain ? gridDim.x : slots;
+    for (; group < g_end; group += g_step) {
+        const u32 packet = group * TW + w;
+        if (packet >= npackets) continue;
         const u32 q0 = packet * 64, q = q0 + lane;
         T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;      // empty box: overlaps nothing
         u32 qid = 0, qskip = END;
@@ -380,7 +391,12 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
                              __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
             const bool is_leaf = idx >= leaf_start;
-            if (STATS) { trips++; leaf_tests += is_leaf; }
+            if (STATS) {
+                trips++; leaf_tests += is_leaf;
+                // how many steps stay within W sorted positions of the block's first leaf (W = 1k, 2k, 4k, 8k)
+                const u32 pos = is_leaf ? idx - leaf_start : idx, b0 = (packet & ~(u32)(TW - 1)) * 64;
+                for (int k = 0; k < 4; k++) win[k] += pos >= b0 && pos < b0 + (1024u << k);
+            }
             u32 next = skip;
             if (hits) {
                 if (is_leaf) { sink.emit(hits, qid, down); if (STATS) leaf_hits++; }
@@ -401,17 +417,18 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     __syncthreads();
     sink.copy_out(s_base + s_cnt[w], sink.count);
     if (STATS) {                       // diagnostics: phase-2 steps, one atomic per block
-        __shared__ unsigned long long s_st[4];
-        if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
+        __shared__ unsigned long long s_st[8];
+        if (threadIdx.x < 8) s_st[threadIdx.x] = 0;
         __syncthreads();
         if (lane == 0) {
             atomicAdd(&s_st[0], (unsigned long long)trips);
             atomicAdd(&s_st[1], (unsigned long long)descents);
             atomicAdd(&s_st[2], (unsigned long long)leaf_tests);
             atomicAdd(&s_st[3], (unsigned long long)leaf_hits);
+            for (int k = 0; k < 4; k++) atomicAdd(&s_st[4 + k], (unsigned long long)win[k]);
         }
         __syncthreads();
-        if (threadIdx.x < 4) atomicAdd(&stats[threadIdx.x], (u64)s_st[threadIdx.x]);
+        if (threadIdx.x < 8) atomicAdd(&stats[threadIdx.x], (u64)s_st[threadIdx.x]);
     }
 }
 
@@ -489,6 +506,7 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     // hardware's 8 waves/SIMD, the rest is instruction issue.  Vector instead of scalar record loads
     // (variant bit 1): 0.112 ms.
     if (g_traverse_variant & 4) g = dim3(blocks > 256 ? 256 : blocks);
+    if (g_traverse_variant & 16) mode |= 8;       // plain packet order
     if (g_traverse_variant == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
     else if (st) k_traverse<T, true, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (g_traverse_variant & 2) k_traverse<T, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
@@ -553,8 +571,8 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     return COL_EINVAL;
 }
 
-// Diagnostics: same traversal, also accumulates stats[0] = phase-2 steps summed over waves,
-// stats[2] = blocks.  mode bit0 skips phase 1, bit1 skips phase 2 (timing ablations only).
+// Diagnostics: same traversal, also accumulates stats[0..7] (8 x u64) = phase-2 steps, descents, leaf
+// tests, leaf hits, and the steps within 1k / 2k / 4k / 8k sorted positions of the block's first leaf.  mode bit0 skips phase 1, bit1 skips phase 2 (timing ablations only).
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                        uint32_t n, int coord_bytes, uint64_t *stats, int mode) {
     if (n < 2) return COL_OK;

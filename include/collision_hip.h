@@ -167,6 +167,7 @@ void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 
 int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192; 0 = automatic).  Set it BEFORE sizing
                                            scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it. */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
+/* stats: 8 x uint64 (steps, descents, leaf tests, leaf hits, steps within 1k/2k/4k/8k positions of the block start) */
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                        const void *bounds, uint32_t n, int coord_bytes, uint64_t *stats, int mode);
 

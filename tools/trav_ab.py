@@ -26,7 +26,7 @@ for name, coords, radii in scenes:
     cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
     col = Collider(ctx, n, 64, 256)
     col.get_collisions(cq, cb, rb, nb, pb, cap); cq.finish()
-    for variant in (0, 8, 0, 8):
+    for variant in (0, 16, 0, 16):
         cdll().col_debug_traverse(variant)
         def run():
             call.col_fill(cq.stream, nb.ptr, z.ctypes.data, 4, 1)
