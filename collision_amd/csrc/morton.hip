@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (blockIdx.x == 0 && tid == 0 && zero_word) *zero_word = 0;
     s_hist[tid] = 0;
+    // this thread's rows first: their loads overlap the fold of the partials below
+    Vec4<T> c[MT_TILE / 256];
+    T rad[MT_TILE / 256];
+#pragma unroll
+    for (int k = 0; k < MT_TILE / 256; k++) {
+        const u32 i = blockIdx.x * MT_TILE + k * 256 + tid;
+        if (i < n) {
+            c[k] = coords[i];
+            if (packed) rad[k] = radii[i];
+        }
+    }
     T acc[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { acc[k] = (T)INFINITY; acc[4 + k] = -(T)INFINITY; }
@@ -124,14 +135,13 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
         if (i >= padded) continue;
         u32 code = 0xFFFFFFFFu;   // collision.py:137-142
         if (i < n) {
-            const Vec4<T> c = coords[i];
             if (packed) {
-                Vec4<T> pr = c;
-                pr.w = radii[i];
+                Vec4<T> pr = c[k];
+                pr.w = rad[k];
                 packed[i] = pr;
             }
-            code = (expand_bits(quantize(c.x, mn.x, mx.x)) << 2) + (expand_bits(quantize(c.y, mn.y, mx.y)) << 1) +
-                   expand_bits(quantize(c.z, mn.z, mx.z));
+            code = (expand_bits(quantize(c[k].x, mn.x, mx.x)) << 2) + (expand_bits(quantize(c[k].y, mn.y, mx.y)) << 1) +
+                   expand_bits(quantize(c[k].z, mn.z, mx.z));
         }
         codes[i] = code;
         if (ids) ids[i] = i;
