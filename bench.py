@@ -355,6 +355,13 @@ def main():
             from collision_amd.stages import stage_times
             extra["stage_ms"] = stage_times(hip, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_buf,
                                             PAIR_CAPACITY)
+            # count-only mode (collision.cl:203-207: capacity 0, no pair buffer)
+            def count_only():
+                collider.get_collisions(cq, coords_buf, radii_buf, n_buf, None, 0)
+            count_only()
+            cq.finish()
+            extra["count_only_ms"] = round(time_events(hip, cq, count_only, 20), 4)
+            extra["count_only_pairs"] = int(hip.read_buffer(cq, n_buf, np.uint32, 1)[0])
             if not args.no_radix:
                 extra["config3_clustered"] = config3_leg(hip, ctx, cq)
                 extra["radix_sort"]["gkeys_per_s_other_distributions"] = config5_variants(hip, ctx, cq)

@@ -86,4 +86,14 @@ def stage_times(hip_mod, ctx, cq, collider, coords_buf, radii_buf, n_buf, pairs_
     out["sort_pass_scatter"] = round(_timed(cq, f_scatter, reps), 4)   # offsets from the scan above
     out["sort_pass_scan"] = round(_timed(cq, f_scan, reps), 4)
     out["whole_path"] = round(_timed(cq, f_all, reps), 4)
+    # the traversal as visited nodes/s -- steps of the wave-uniform walk (each tests one
+    # node record against a packet of 64 queries), from the counting instance of the kernel
+    f_lbvh()
+    stats = hip.Buffer(ctx, hostbuf=np.zeros(8, np.uint64))
+    call.col_fill(s, n_buf.ptr, zero.ctypes.data, 4, 1)
+    call.col_traverse_stats(s, pairs_buf.ptr, n_buf.ptr, capacity, bounds.ptr, n, cb, stats.ptr, 0)
+    st = hip.read_buffer(cq, stats, np.uint64, 8)
+    out["traverse_walk_steps"] = int(st[0])
+    out["traverse_node_visits_per_s"] = float(st[0]) / (out["traverse"] * 1e-3)
+    out["traverse_box_tests_per_s"] = 64.0 * float(st[0]) / (out["traverse"] * 1e-3)
     return out
