@@ -87,6 +87,11 @@ _PROTOS = {
                                   C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_fold_boxes": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "col_sample_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_splitters_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_digit_counts": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_expand_counts": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_radix": (C.c_int, [C.c_int]),

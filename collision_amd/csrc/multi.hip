@@ -206,9 +206,119 @@ __global__ __launch_bounds__(256) void k_translate(u32 *__restrict__ pairs, cons
         pairs[i] = gids[pairs[i]];
 }
 
+// ---- small protocol steps (one launch each instead of chains of tensor-library calls) ----
+
+// fold `count` gathered [min row, max row] boxes into one
+__global__ __launch_bounds__(64) void k_fold_boxes(const float *__restrict__ boxes, u32 count, float *__restrict__ out) {
+    const u32 k = threadIdx.x;
+    if (k >= 8) return;
+    float acc = k < 4 ? INFINITY : -INFINITY;
+    for (u32 i = 0; i < count; i++) {
+        const float v = boxes[8ull * i + k];
+        acc = k < 4 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+    }
+    out[k] = acc;
+}
+
+// `samples` evenly strided elements of codes[0..n) (the codes are in id-hash order: a strided sample
+// is a random sample); an empty rank contributes the code ceiling
+__global__ __launch_bounds__(256) void k_sample(const u32 *__restrict__ codes, u32 n, u32 samples, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= samples) return;
+    out[i] = n ? codes[samples > 1 ? (u32)(((u64)i * (n - 1)) / (samples - 1)) : 0u] : (1u << 30);
+}
+
+// world - 1 splitters = quantiles of the `count` gathered samples (count <= SPL_MAX): one block sorts
+// them in LDS (bitonic) and picks every (count / world)-th
+constexpr u32 SPL_MAX = 8192;
+__global__ __launch_bounds__(1024) void k_splitters(const u32 *__restrict__ samples, u32 count, u32 world,
+                                                     u32 *__restrict__ out) {
+    __shared__ u32 s[SPL_MAX];
+    u32 m = 1;
+    while (m < count) m <<= 1;
+    for (u32 i = threadIdx.x; i < m; i += 1024) s[i] = i < count ? samples[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 k = 2; k <= m; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = threadIdx.x; i < m; i += 1024) {
+                const u32 l = i ^ j;
+                if (l > i) {
+                    const u32 a = s[i], b = s[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const u32 step = count / world;
+    for (u32 q = threadIdx.x + 1; q < world; q += 1024) out[q - 1] = s[q * step];
+}
+
+// spheres per destination from the SCANNED digit-major histogram of the owner pass: the run of digit q
+// starts at scanned[q * nb]
+__global__ __launch_bounds__(256) void k_digit_counts(const u32 *__restrict__ scanned, u32 nb, u32 world, u32 n,
+                                                       u32 *__restrict__ out) {
+    const u32 q = threadIdx.x;
+    if (q >= world) return;
+    const u32 lo = scanned[(u64)q * nb], hi = q + 1 < 256 ? scanned[(u64)(q + 1) * nb] : n;
+    out[q] = hi - lo;
+}
+
+// per-rank send counts of the halo exchange: out[peer k] = counts[k], 0 elsewhere
+__global__ __launch_bounds__(256) void k_expand_counts(const u32 *__restrict__ counts, PeerList pl, u32 world,
+                                                        u32 *__restrict__ out) {
+    const u32 q = threadIdx.x;
+    if (q >= world) return;
+    u32 v = 0;
+    for (int k = 0; k < pl.n; k++)
+        if ((u32)pl.q[k] == q) v = counts[k];
+    out[q] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int col_fold_boxes(void *stream, const void *boxes, uint32_t count, void *out8) {
+    k_fold_boxes<<<dim3(1), dim3(64), 0, col_stream(stream)>>>((const float *)boxes, count, (float *)out8);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_sample_u32(void *stream, const uint32_t *codes, uint32_t n, uint32_t samples, uint32_t *out) {
+    if (samples == 0) return COL_OK;
+    k_sample<<<dim3((unsigned)col_ceil_div(samples, 256)), dim3(256), 0, col_stream(stream)>>>(codes, n, samples, out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out) {
+    if (world < 2) return COL_OK;
+    if (count == 0 || count > SPL_MAX || count < world) return COL_EINVAL;
+    k_splitters<<<dim3(1), dim3(1024), 0, col_stream(stream)>>>(samples, count, world, out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
+                     uint32_t *out) {
+    if (world == 0 || world > 256) return COL_EINVAL;
+    k_digit_counts<<<dim3(1), dim3(256), 0, col_stream(stream)>>>(scanned_hist, nblocks, world, n, out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_expand_counts(void *stream, const uint32_t *counts, const int *peers, int n_peers, uint32_t world,
+                      uint32_t *out) {
+    if (n_peers < 0 || n_peers > 8 || world == 0 || world > 256) return COL_EINVAL;
+    PeerList pl;
+    pl.n = n_peers;
+    for (int k = 0; k < 8; k++) pl.q[k] = k < n_peers ? peers[k] : -1;
+    k_expand_counts<<<dim3(1), dim3(256), 0, col_stream(stream)>>>(counts, pl, world, out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
 
 int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids, const uint32_t *idx,
                      uint32_t n, void *rows, uint32_t *out_gids) {

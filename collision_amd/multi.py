@@ -93,7 +93,7 @@ class Exchange:
     def exchange_counts(self, send_counts_dev):
         """send_counts_dev: device tensor [world], entry q = rows I send to q.  One all-gather and one
         host sync give both directions: (send_counts, recv_counts) as Python lists."""
-        mat = self.all_gather(send_counts_dev.to(self.torch.int64)).cpu()
+        mat = self.all_gather(send_counts_dev).cpu()
         return [int(v) for v in mat[self.rank].tolist()], [int(v) for v in mat[:, self.rank].tolist()]
 
     def all_to_all_v(self, send, send_counts, recv, recv_counts):
@@ -131,7 +131,40 @@ class Exchange:
 
 
 # --------------------------------------------------------------------------- device engine
-class HipEngine:
+class ProtocolOps:
+    """The small tensor steps between the collectives, written with tensor-library calls.  HipEngine
+    replaces each of them by ONE launch through the C ABI; the CPU test double keeps these."""
+
+    def fold_ranges(self, ranges):
+        """[R, 8] gathered (min row, max row) boxes -> [8]."""
+        torch = self.torch
+        return torch.cat([ranges[:, :4].min(dim=0).values, ranges[:, 4:].max(dim=0).values]).contiguous()
+
+    def sample_codes(self, codes, n):
+        """SAMPLES evenly strided codes (int32 tensor); an empty rank contributes the code ceiling."""
+        torch = self.torch
+        if n == 0:
+            return torch.full((SAMPLES,), 1 << 30, dtype=torch.int32, device=codes.device)
+        pos = (torch.arange(SAMPLES, device=codes.device, dtype=torch.int64) * (n - 1)) // (SAMPLES - 1)
+        return codes[pos].contiguous()
+
+    def splitters(self, allsamples, world):
+        """world - 1 quantiles of the gathered samples (uint32 order), as an int32 tensor."""
+        torch = self.torch
+        flat = (allsamples.reshape(-1).to(torch.int64) & 0xFFFFFFFF).sort().values
+        cut = torch.arange(1, world, device=flat.device, dtype=torch.int64) * (flat.numel() // world)
+        return flat[cut].to(torch.int32).contiguous()
+
+    def expand_counts(self, counts, peers, world):
+        """int32[world]: counts[k] at index peers[k], 0 elsewhere."""
+        torch = self.torch
+        out = torch.zeros(world, dtype=torch.int32, device=counts.device)
+        if peers:
+            out[torch.tensor(peers, device=counts.device)] = counts[:len(peers)].to(torch.int32)
+        return out
+
+
+class HipEngine(ProtocolOps):
     """Device work of one rank through the C ABI, on torch CUDA tensors (torch = memory + stream)."""
 
     def __init__(self, ctx, capacity, group_size, pair_capacity, ghost_capacity):
@@ -172,7 +205,9 @@ class HipEngine:
         self.pairs = torch.zeros((pair_capacity, 2), dtype=i32, device=dev)
         self.counter = ints(1)
         self.range8 = torch.zeros(8, dtype=f32, device=dev)
+        self.grange8 = torch.zeros(8, dtype=f32, device=dev)
         self.box8 = torch.zeros(8, dtype=f32, device=dev)
+        self.sample, self.split, self.owner_counts, self.rank_counts = ints(SAMPLES), ints(256), ints(256), ints(256)
         self.collider = Collider(ctx, capacity, 64, group_size)
         self.collider._allocate()
         self._reduce_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(0, 4))
@@ -201,6 +236,24 @@ class HipEngine:
             call.col_reduce(self.cq.stream, rows.data_ptr(), n, 0, 4, 0, self._reduce_scratch.ptr, self.range8.data_ptr())
         return self.range8
 
+    def fold_ranges(self, ranges):
+        call.col_fold_boxes(self.cq.stream, ranges.data_ptr(), int(ranges.shape[0]), self.grange8.data_ptr())
+        return self.grange8
+
+    def sample_codes(self, codes, n):
+        call.col_sample_u32(self.cq.stream, codes.data_ptr(), n, SAMPLES, self.sample.data_ptr())
+        return self.sample
+
+    def splitters(self, allsamples, world):
+        flat = allsamples.reshape(-1)
+        call.col_splitters_u32(self.cq.stream, flat.data_ptr(), int(flat.numel()), world, self.split.data_ptr())
+        return self.split[:world - 1]
+
+    def expand_counts(self, counts, peers, world):
+        arr = (C.c_int * max(len(peers), 1))(*peers)
+        call.col_expand_counts(self.cq.stream, counts.data_ptr(), arr, len(peers), world, self.rank_counts.data_ptr())
+        return self.rank_counts[:world]
+
     def codes_of(self, rows, n, range8):
         """Morton codes of the rows under the global scene range (unsorted) + the index ramp."""
         call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), n, n, 4, self.codes.data_ptr(),
@@ -219,11 +272,11 @@ class HipEngine:
         if n == 0:
             return self.perm, torch.zeros(world, dtype=torch.int32, device=self.device)
         call.col_radix_histogram(s, self.dest.data_ptr(), n, 4, 4, 0, hist.data_ptr())
-        counts = hist.view(256, nb)[:world].sum(dim=1, dtype=torch.int32)
         call.col_scan_u32(s, hist.data_ptr(), 256 * nb, self._scan_scratch.ptr)
+        call.col_digit_counts(s, hist.data_ptr(), nb, world, n, self.owner_counts.data_ptr())
         call.col_radix_scatter(s, self.dest.data_ptr(), self.codes_sorted.data_ptr(), self.iota.data_ptr(),
                                self.perm.data_ptr(), n, 4, 4, 0, hist.data_ptr())
-        return self.perm, counts
+        return self.perm, self.owner_counts[:world]
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         """out5[out_offset + i] = (rows[idx[idx_offset + i]], gids[...]) for i < n (idx None = identity)."""
@@ -239,9 +292,9 @@ class HipEngine:
         """Single-GPU path on the owned spheres; pairs come out as global ids."""
         s = self.cq.stream
         self.n_owned = n
-        self.counter.zero_()
         if n == 0:
-            return
+            self.counter.zero_()
+            return                                # (col_collide zeroes the counter itself)
         c = self.collider
         if rows is not self.owned_rows:           # owned rows come out of unpack5 with radii already split off
             call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
@@ -324,7 +377,7 @@ class DistributedCollider:
 
         # 1. global scene range of the centres (AABB all-gather #1)
         ranges = x.all_gather(e.centre_range(rows, n))                 # [R, 8]
-        grange = torch.cat([ranges[:, :4].min(dim=0).values, ranges[:, 4:].max(dim=0).values]).contiguous()
+        grange = e.fold_ranges(ranges)
 
         # 2. spatial repartition
         if self.partition == "morton" and (R > 1 or self.exercise):
@@ -355,11 +408,12 @@ class DistributedCollider:
         peers = [q for q in range(R) if handles(q, r, R)]
         if len(peers) > e.max_peers:
             raise NotImplementedError("more than %d halo peers per rank" % e.max_peers)
-        per_rank = torch.zeros(R, dtype=torch.int32, device=boxes.device)
         if peers:
             lists, stride, counts = e.select_multi(own_rows, m, boxes, peers)
             e.pack5_lists(own_rows, own_gids, lists, stride, counts, len(peers), m, e.halo5)
-            per_rank[torch.tensor(peers, device=boxes.device)] = counts[:len(peers)].to(torch.int32)
+            per_rank = e.expand_counts(counts, peers, R)
+        else:
+            per_rank = torch.zeros(R, dtype=torch.int32, device=boxes.device)
         send_counts, recv_counts = x.exchange_counts(per_rank)                     # the step's 2nd host sync
         g = sum(recv_counts)
         if sum(send_counts) > self.ghost_capacity or g > self.ghost_capacity:
@@ -375,15 +429,8 @@ class DistributedCollider:
     def _splitters(self, codes, n):
         """R-1 global quantiles of the Morton codes from SAMPLES strided local samples (the codes are
         in input order, i.e. id-hash order: a strided sample is a random sample)."""
-        torch, R = self.x.torch, self.world
-        if n > 0:
-            pos = torch.linspace(0, n - 1, SAMPLES, device=codes.device).long()
-            sample = codes[pos].to(torch.int64)
-        else:
-            sample = torch.full((SAMPLES,), 1 << 30, dtype=torch.int64, device=codes.device)
-        allsamp = self.x.all_gather(sample).reshape(-1).sort().values
-        cut = (torch.arange(1, R, device=allsamp.device) * (allsamp.numel() // R)).long()
-        return allsamp[cut].to(torch.int32).contiguous()
+        e = self.engine
+        return e.splitters(self.x.all_gather(e.sample_codes(codes, n)), self.world)
 
     # -- results -------------------------------------------------------------------------------
     def synchronize(self):

@@ -226,6 +226,20 @@ int col_traverse_ghost(void *stream, const void *ghost_rows, const uint32_t *gho
 int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first,
                         uint32_t capacity, const uint32_t *gids);
 
+/* Small steps of the multi-GPU protocol (collision_amd/multi.py), one launch each:
+ *   col_fold_boxes     out8 = [min of the min rows, max of the max rows] of `count` gathered boxes
+ *   col_sample_u32     out[i] = codes[i * (n - 1) / (samples - 1)]  (n == 0: 1 << 30)
+ *   col_splitters_u32  world - 1 quantiles of `count` <= 8192 gathered samples (sorted on the device)
+ *   col_digit_counts   elements per digit from the scanned digit-major histogram of a radix pass
+ *   col_expand_counts  out[peers[k]] = counts[k], 0 for the other ranks                        */
+int col_fold_boxes(void *stream, const void *boxes, uint32_t count, void *out8);
+int col_sample_u32(void *stream, const uint32_t *codes, uint32_t n, uint32_t samples, uint32_t *out);
+int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out);
+int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
+                     uint32_t *out);
+int col_expand_counts(void *stream, const uint32_t *counts, const int *peers, int n_peers, uint32_t world,
+                      uint32_t *out);
+
 /* ---------------------------------------------------------------- index / offset
  * collision/index.cl:1-13 (Indexer.gather/scatter, index.py:23-55) and
  * collision/offset.cl:3-12 (OffsetFinder.find_offsets, offset.py:37-49). */

@@ -18,8 +18,14 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-class OracleEngine:
-    """CPU stand-in for collision_amd.multi.HipEngine (same methods, torch CPU tensors)."""
+def _protocol_ops():
+    from collision_amd.multi import ProtocolOps
+    return ProtocolOps
+
+
+class OracleEngine(_protocol_ops()):
+    """CPU stand-in for collision_amd.multi.HipEngine (same methods, torch CPU tensors); the small
+    tensor steps between the collectives are ProtocolOps' tensor-library versions."""
 
     def __init__(self, capacity, pair_capacity, ghost_capacity):
         import torch
