@@ -61,10 +61,11 @@ __device__ __forceinline__ u64 match8(u32 d) {
     u32 dlo = 0, dhi = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const u32 m = (u32)__builtin_amdgcn_sbfe(d, b, 1);        // my bit b replicated: 0 or ~0
-        const u64 bal = __ballot(m != 0);                         // lanes whose bit b is set
-        dlo |= (u32)bal ^ m;                                      // lanes that differ from me in bit b:
-        dhi |= (u32)(bal >> 32) ^ m;                              //   ~bal if my bit is set, bal if it is clear
+        const u32 m = (u32)__builtin_amdgcn_sbfe(d, b, 1);                  // my bit, replicated
+        const u64 bal = __builtin_amdgcn_ballot_w64(m != 0);
+        // acc | (ballot ^ mine) in one v_bitop3 per half (truth table 0xF6 for (acc, ballot, mine))
+        dlo = __builtin_amdgcn_bitop3_b32(dlo, (u32)bal, m, 0xF6);
+        dhi = __builtin_amdgcn_bitop3_b32(dhi, (u32)(bal >> 32), m, 0xF6);
     }
     return ~(((u64)dhi << 32) | dlo);
 }
