@@ -216,3 +216,15 @@ def test_twenty_million_spheres_match_oracle(oracle, hip_env):
     radii = np.full(n, 0.0004, dtype="float32")
     _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256, ngroups=64, capacity=1 << 23)
     assert abs(count - n * n / 2 * (4 * 0.0004) ** 3) < 0.05 * count          # ~819 k pairs
+
+
+def test_three_million_spheres_match_oracle(oracle, hip_env):
+    """3 M spheres: the 4096-pair radix tile with the unfused front end (bounds -> Morton -> histogram as
+    separate launches), 11 719 LBVH chunks = 46 groups whose table is built while the top level is
+    scanned linearly; every array bit for bit against the oracle."""
+    n = 3000000
+    rng = np.random.RandomState(11)
+    coords = rng.random_sample((n, 3)).astype("float32")
+    radii = np.full(n, 0.0007, dtype="float32")
+    _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256, ngroups=64, capacity=1 << 21)
+    assert abs(count - n * n / 2 * (4 * 0.0007) ** 3) < 0.05 * count          # ~99 k pairs
