@@ -229,17 +229,6 @@ __global__ __launch_bounds__(256) void k_refit_finish(T *__restrict__ bounds, u3
 //            the same for all 64 queries, so one uniform walk serves them all: one 32-byte
 //            record per step at a wave-uniform address, descend iff ANY lane's box overlaps.
 // Hits are appended with one atomic per candidate (ballot + mbcnt).
-template <typename T> __device__ __forceinline__ T readlane_t(T v, int l);
-template <> __device__ __forceinline__ float readlane_t(float v, int l) {
-    return __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
-}
-template <> __device__ __forceinline__ double readlane_t(double v, int l) {
-    const u64 b = (u64)__double_as_longlong(v);
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, l);
-    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(b >> 32), l);
-    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
-}
-
 // Pair output.  One global counter cannot take an atomic per hit: a single address retires
 // ~88 atomics/us on MI355X, and the first version of this kernel spent 0.3 ms of 0.39 ms there
 // for 32 k pairs.  Hits are staged in a wave-private LDS buffer; a wave flushes it with ONE
@@ -270,15 +259,13 @@ struct PairSink {
         copy_out(base, count);
         count = 0;
     }
-    // `hits` is wave-uniform and non-zero; lanes set in it append (qid, pid)
+    // `hits` is wave-uniform and non-zero; lanes set in it append their own (qid, pid)
     __device__ __forceinline__ void emit(u64 hits, u32 qid, u32 pid) {
         const u32 add = (u32)__popcll(hits);
         if (count + add > (u32)CAPW) flush();
         if ((hits >> lane) & 1ull) buf[count + mbcnt(hits)] = make_uint2(qid, pid);
         count += add;
     }
-    // same, but every hitting lane brings its own partner id
-    __device__ __forceinline__ void emit_each(u64 hits, u32 qid, u32 pid) { emit(hits, qid, pid); }
 };
 
 // STATS: count phase-2 steps for col_traverse_stats (diagnostics); the production instance carries
@@ -472,7 +459,7 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
                 idx = (overlap && !leaf) ? down : skip;
             }
             const u64 hits = __ballot(hit);
-            if (hits) sink.emit_each(hits, qid, down);
+            if (hits) sink.emit(hits, qid, down);
         }
     }
     if (lane == 0) s_cnt[w] = sink.count;

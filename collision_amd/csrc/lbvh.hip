@@ -348,7 +348,6 @@ constexpr u32 LIN = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
                                                const T *__restrict__ partial, Tabs tabs, u32 n, int lin) {
-    typedef typename BT<T>::V4 V4;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i + 1 >= n) return;
     const u32 j = other_end[i];

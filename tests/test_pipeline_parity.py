@@ -33,8 +33,10 @@ def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=
     dt = coords.dtype
     n = len(coords)
     collider = Collider(ctx, n, ngroups, group_size, dt)
-    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size,
-                         capacity=capacity if capacity is not None else max(64 * n, min(n * (n - 1) // 2, 1 << 22)))
+    first_cap = capacity if capacity is not None else max(64 * n, min(n * (n - 1) // 2, 1 << 22))
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=first_cap)
+    if capacity is None and ref["count"] > first_cap:          # dense scene: the oracle's list was cut short
+        ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=ref["count"])
     cap = ref["count"] if capacity is None else capacity
     count, pairs = run_collider(ctx, cq, collider, coords, radii, cap)
     st = collider_state(cq, collider)
