@@ -339,7 +339,10 @@ def main():
             extra["radix_sort"] = {"n_keys": rb["n_keys"], "key": "u32 (30-bit, Morton-like)", "value": "u32",
                                    "gkeys_per_s": round(rb["gkeys_per_s"], 3), "sort_ms": round(rb["sort_ms"], 4),
                                    "hist_ms": round(rb["hist_ms"], 4),
-                                   "scatter_ms_top_digit": round(rb["scatter_ms_top_digit"], 4)}
+                                   "scatter_ms_top_digit": round(rb["scatter_ms_top_digit"], 4),
+                                   # passes x (scatter bytes + histogram read of the keys)
+                                   "algo_bytes_whole_sort": 4 * (16 + 4) * rb["n_keys"],
+                                   "whole_sort_gbs": round(4 * (16 + 4) * rb["n_keys"] / rb["sort_ms"] / 1e6, 1)}
             roofline = {"bound": "hbm", "kernel": "radix k_scatter<u32 key, 4-byte value, 16 items, 512 threads> "
                                                    "(64Mi pairs, 8-bit digit, pass 0, tile %d)" % rb["tile"],
                         "achieved": round(rb["scatter_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
