@@ -7,6 +7,8 @@ Collider :32-198): same constructor, ``resize``, ``n_nodes``, ``padded_size`` an
 wait_for)``, same ``ValueError`` contract.  The ~76 PyOpenCL enqueues of the reference become one
 C-ABI call, ``col_collide``, which enqueues the whole chain on the caller's HIP stream.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import hip
@@ -58,6 +60,14 @@ class Collider:
                 raise ValueError("Collider and program coord_dtype must match")
         self.program = program
         self._alloc = {}              # device scratch, (re)allocated at first use after a size change
+        # Sort plan for inputs below 1 Mi spheres (include/collision_hip.h, col_collide_plan): the MSD sort
+        # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
+        # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
+        # then take the LSD sort, and the MSD one is tried again every PLAN_RETRY calls.  No host sync: the
+        # word is read when the next call is made.  sort_plan = "lsd" / "msd" pins the choice.
+        self.sort_plan = "auto"
+        self._plan_word = None
+        self._lsd_calls_left = 0
 
     # -- sizes -----------------------------------------------------------------
     @property
@@ -110,10 +120,39 @@ class Collider:
             raise ValueError("Invalid collisions_buf for n_collisions > 0")
         self._allocate()
         cq.wait_for(wait_for)
-        call.col_collide(
+        call.col_collide_plan(
             cq.stream, coords_buf.ptr, radii_buf.ptr, self.size, self.padded_size,
             self.program.coord_dtype.itemsize,
             self._codes_bufs[0].ptr, self._codes_bufs[1].ptr, self._ids_bufs[0].ptr, self._ids_bufs[1].ptr,
             self._nodes_buf.ptr, self._bounds_buf.ptr, self._flags_buf.ptr, self._alloc["scratch"].ptr,
-            n_collisions_buf.ptr, None if collisions_buf is None else collisions_buf.ptr, n_collisions)
+            n_collisions_buf.ptr, None if collisions_buf is None else collisions_buf.ptr, n_collisions,
+            self._choose_sort_plan(), self._plan_word)
         return hip.Event(cq)
+
+    PLAN_RETRY = 64
+
+    def _choose_sort_plan(self):
+        """0 = LSD, 1 = MSD (see __init__)."""
+        if self.sort_plan != "auto":
+            return 1 if self.sort_plan == "msd" else 0
+        if self._plan_word is None:
+            word = C.c_void_p()
+            call.col_host_alloc(C.byref(word), 64)
+            self._plan_word = word.value
+            C.c_uint32.from_address(self._plan_word).value = 0
+        flag = C.c_uint32.from_address(self._plan_word)
+        if flag.value:                               # an earlier call met a bucket that did not fit
+            flag.value = 0
+            self._lsd_calls_left = self.PLAN_RETRY
+        if self._lsd_calls_left:
+            self._lsd_calls_left -= 1
+            return 0
+        return 1
+
+    def __del__(self):
+        word, self._plan_word = getattr(self, "_plan_word", None), None
+        if word:
+            try:
+                call.col_host_free(word)
+            except Exception:
+                pass

@@ -577,6 +577,14 @@ size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
 int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
                 uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
                 uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity) {
+    return col_collide_plan(stream, coords, radii, n, padded, coord_bytes, codes0, codes1, ids0, ids1, nodes, bounds, flags,
+                            scratch, counter, pairs, capacity, COL_SORT_LSD, nullptr);
+}
+
+int col_collide_plan(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
+                     uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
+                     uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,
+                     int sort_plan, uint32_t *oversize) {
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
@@ -600,10 +608,13 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
         // small inputs are launch-bound: the Morton kernel folds the bounds partials itself and counts
         // the sort's pass-0 digits (the histogram sits at the start of the sort scratch): two launches less
         uint32_t parts = 0;
+        const bool msd = sort_plan == COL_SORT_MSD;
         if ((rc = col_minmax4_stage1(stream, coords, n, coord_bytes, red_scratch, &parts))) return rc;
         if ((rc = col_morton_tile(stream, coords, radii, red_scratch, parts, n, padded, coord_bytes, codes0, ids0, packed,
-                                  counter, (uint32_t *)sort_scratch, (uint32_t)col_ceil_div(padded, 1024)))) return rc;
-        if ((rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1))) return rc;
+                                  counter, (uint32_t *)sort_scratch, (uint32_t)col_ceil_div(padded, 1024), msd ? 22 : 0))) return rc;
+        if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
+        else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
+        if (rc) return rc;
     } else {
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
         if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;

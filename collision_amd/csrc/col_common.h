@@ -30,7 +30,8 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 //  * col_minmax4_stage1: stage 1 of col_reduce(MINMAX, width 4) only; `parts` partial results of
 //    [min row, max row] are left in `partials` (at most COL_MINMAX_PARTS of them);
 //  * col_morton_tile: col_morton_ex that folds those partials itself (no stage-2 launch) and also
-//    writes the pass-0 histogram of the radix sort, tile = 1024 codes per block, digit-major
+//    writes a histogram for the radix sort (digit = bits hist_shift..hist_shift+7: 0 for the LSD sort's
+//    pass 0, 22 for the MSD sort's bucket digit), tile = 1024 codes per block, digit-major
 //    hist[d * nblocks + b] like k_hist;
 //  * col_radix_sort_ex(have_hist0 = 1): col_radix_sort that finds the pass-0 histogram already at the
 //    start of `scratch`.
@@ -38,7 +39,9 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                               uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks);
+                               uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks, int hist_shift);
+extern "C" int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
+                                  uint32_t *vals_out, uint64_t n, void *scratch, uint32_t *oversize);
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 

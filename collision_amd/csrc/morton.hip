@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
                                                       u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
                                                       u32 *__restrict__ ids, const T *__restrict__ radii,
                                                       Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
-                                                      u32 *__restrict__ hist0, u32 nblocks) {
+                                                      u32 *__restrict__ hist0, u32 nblocks, int hist_shift) {
     __shared__ T s_fold[4][8];
     __shared__ u32 s_hist[256];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
         }
         codes[i] = code;
         if (ids) ids[i] = i;
-        atomicAdd(&s_hist[code & 255u], 1u);
+        atomicAdd(&s_hist[(code >> hist_shift) & 255u], 1u);
     }
     __syncthreads();
     hist0[(uint64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
@@ -157,8 +157,8 @@ extern "C" {
 
 int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                     uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                    uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks) {
-    if (padded < n || parts == 0 || !hist0) return COL_EINVAL;
+                    uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks, int hist_shift) {
+    if (padded < n || parts == 0 || !hist0 || hist_shift < 0 || hist_shift > 24) return COL_EINVAL;
     if (padded == 0) return COL_OK;
     if (packed && !radii) return COL_EINVAL;
     if (nblocks != (uint32_t)col_ceil_div(padded, MT_TILE)) return COL_EINVAL;
@@ -166,11 +166,11 @@ int col_morton_tile(void *stream, const void *coords, const void *radii, const v
     if (coord_bytes == 4)
         k_morton_tile<float><<<grid, block, 0, col_stream(stream)>>>((const Vec4<float> *)coords, (const float *)partials, parts,
                                                                      n, padded, codes, ids, (const float *)radii,
-                                                                     (Vec4<float> *)packed, zero_word, hist0, nblocks);
+                                                                     (Vec4<float> *)packed, zero_word, hist0, nblocks, hist_shift);
     else if (coord_bytes == 8)
         k_morton_tile<double><<<grid, block, 0, col_stream(stream)>>>((const Vec4<double> *)coords, (const double *)partials,
                                                                       parts, n, padded, codes, ids, (const double *)radii,
-                                                                      (Vec4<double> *)packed, zero_word, hist0, nblocks);
+                                                                      (Vec4<double> *)packed, zero_word, hist0, nblocks, hist_shift);
     else
         return COL_EINVAL;
     COL_LAUNCH_OK();

@@ -316,6 +316,166 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     STAMP(4)      // read back + global stores (issue only)
 }
 
+// ---- MSD finish: one block sorts one top-digit bucket on its remaining low bits ----
+// col_radix_sort_msd (small inputs, launch-bound): ONE global pass on the top 8 significant bits
+// (k_scatter, shift BS_SHIFT) leaves 256 buckets; a bucket of up to BS_CAP pairs is then sorted on
+// the low BS_SHIFT bits entirely in LDS (three stable 8-bit LSD passes, ranking as in k_scatter), which
+// replaces three global passes of three launches each.  A larger bucket (clustered codes) takes the
+// same three passes through global memory, chunk by chunk, by its one block: correct but slow, and
+// reported through *oversize so that the caller goes back to the LSD sort.
+constexpr int BS_NT = 512, BS_IT = 16, BS_NW = BS_NT / COL_WAVE;
+constexpr u32 BS_CAP = BS_NT * BS_IT;          // 8192 pairs
+constexpr int BS_SHIFT = 22;                   // bucket digit = bits 22..29 of a 30-bit Morton code (pads: 255)
+constexpr int BS_ROW = COL_WAVE * BS_IT;       // positions per wave
+
+struct BucketLds {
+    u32 keys[BS_CAP];
+    u32 vals[BS_CAP];
+    u32 cnt[BS_NW][RDIG];
+    u32 base[RDIG];
+    u32 ws[BS_NW];
+};
+
+// One stable pass over the (up to BS_CAP) pairs held lane-striped in registers: position of item k of
+// this thread = w * BS_ROW + k * 64 + lane; rows at or beyond `m` hold pads (key 0xFFFFFFFF) and are
+// skipped.  On return pos[k] = rank of the item inside its (wave, digit) group and lds.cnt[i][d] = number
+// of ranked items (pads of a partly valid row included) of wave i with digit d.
+__device__ __forceinline__ void bucket_rank(BucketLds &lds, const u32 (&key)[BS_IT], u32 (&pos)[BS_IT], u32 m, int shift,
+                                            u32 w, u32 tid) {
+    for (u32 i = tid; i < BS_NW * RDIG; i += BS_NT) (&lds.cnt[0][0])[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BS_IT; k++) {
+        pos[k] = 0;
+        if (w * BS_ROW + k * COL_WAVE >= m) continue;            // wave-uniform: a row of pads only
+        const u32 d = digit_of(key[k], shift);
+        const u64 peers = match8(d);
+        const u32 below = mbcnt(peers);
+        const u32 prev = lds.cnt[w][d];
+        if (below == 0) lds.cnt[w][d] = prev + (u32)__popcll(peers);
+        pos[k] = prev + below;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u32 *__restrict__ v_a, u32 *__restrict__ k_b,
+                                                        u32 *__restrict__ v_b, u32 n, const u32 *__restrict__ offsets,
+                                                        u32 nblocks, u32 *oversize) {
+    __shared__ BucketLds lds;
+    const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1);
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid / COL_WAVE));
+    const u32 d = blockIdx.x;
+    const u32 start = offsets[(uint64_t)d * nblocks], end = d + 1 < RDIG ? offsets[(uint64_t)(d + 1) * nblocks] : n;
+    const u32 S = end - start;
+    if (S == 0) return;
+    u32 key[BS_IT], val[BS_IT], pos[BS_IT];
+
+    if (S <= BS_CAP) {
+#pragma unroll
+        for (int k = 0; k < BS_IT; k++) {
+            const u32 p = w * BS_ROW + k * COL_WAVE + lane;
+            key[k] = p < S ? k_a[start + p] : 0xFFFFFFFFu;
+            val[k] = p < S ? v_a[start + p] : 0u;
+        }
+        for (int shift = 0; shift < BS_SHIFT; shift += 8) {
+            bucket_rank(lds, key, pos, S, shift, w, tid);
+            {   // exclusive over (digit, wave): digit `tid`
+                u32 c[BS_NW], tot = 0;
+                if (tid < RDIG) {
+#pragma unroll
+                    for (int i = 0; i < BS_NW; i++) { c[i] = lds.cnt[i][tid]; tot += c[i]; }
+                }
+                u32 total;
+                const u32 dstart = block_excl_scan<BS_NT>(tot, lds.ws, &total);
+                if (tid < RDIG) {
+                    u32 run = dstart;
+#pragma unroll
+                    for (int i = 0; i < BS_NW; i++) { lds.cnt[i][tid] = run; run += c[i]; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BS_IT; k++) {
+                if (w * BS_ROW + k * COL_WAVE >= S) continue;
+                const u32 q = pos[k] + lds.cnt[w][digit_of(key[k], shift)];
+                lds.keys[q] = key[k];
+                lds.vals[q] = val[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BS_IT; k++) {
+                const u32 p = w * BS_ROW + k * COL_WAVE + lane;
+                if (w * BS_ROW + k * COL_WAVE >= S) continue;
+                key[k] = p < S ? lds.keys[p] : 0xFFFFFFFFu;       // pads of the last row sorted last: drop them again
+                val[k] = p < S ? lds.vals[p] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BS_IT; k++) {
+            const u32 p = w * BS_ROW + k * COL_WAVE + lane;
+            if (p < S) { k_b[start + p] = key[k]; v_b[start + p] = val[k]; }
+        }
+        return;
+    }
+
+    // oversize bucket: the same three passes through global memory, a -> b -> a -> b
+    if (tid == 0 && oversize) *oversize = S;
+    int pass = 0;
+    for (int shift = 0; shift < BS_SHIFT; shift += 8, pass++) {
+        const u32 *sk = ((pass & 1) ? k_b : k_a) + start, *sv = ((pass & 1) ? v_b : v_a) + start;
+        u32 *dk = ((pass & 1) ? k_a : k_b) + start, *dv = ((pass & 1) ? v_a : v_b) + start;
+        if (tid < RDIG) lds.base[tid] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < S; i += BS_NT) atomicAdd(&lds.base[digit_of(sk[i], shift)], 1u);
+        __syncthreads();
+        {
+            u32 total;
+            const u32 mine = tid < RDIG ? lds.base[tid] : 0u;
+            const u32 ex = block_excl_scan<BS_NT>(mine, lds.ws, &total);
+            if (tid < RDIG) lds.base[tid] = ex;                  // where digit `tid` starts in the bucket
+        }
+        __syncthreads();
+        for (u32 c0 = 0; c0 < S; c0 += BS_CAP) {
+            const u32 m = min(BS_CAP, S - c0);
+#pragma unroll
+            for (int k = 0; k < BS_IT; k++) {
+                const u32 p = w * BS_ROW + k * COL_WAVE + lane;
+                key[k] = p < m ? sk[c0 + p] : 0xFFFFFFFFu;
+                val[k] = p < m ? sv[c0 + p] : 0u;
+            }
+            bucket_rank(lds, key, pos, m, shift, w, tid);
+            if (tid < RDIG) {
+                // this chunk's (wave, digit) groups start where the digit's running offset stands; pads (digit
+                // 255 in every pass, ranked after the real items of their row) do not advance it
+                u32 run = lds.base[tid];
+#pragma unroll
+                for (int i = 0; i < BS_NW; i++) { const u32 c = lds.cnt[i][tid]; lds.cnt[i][tid] = run; run += c; }
+                if (tid == RDIG - 1) {
+                    const u32 ranked = ((m + COL_WAVE - 1) / COL_WAVE) * COL_WAVE;     // rows are ranked whole
+                    run -= ranked - m;
+                }
+                lds.base[tid] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BS_IT; k++) {
+                const u32 p = w * BS_ROW + k * COL_WAVE + lane;
+                if (p < m) {
+                    const u32 q = pos[k] + lds.cnt[w][digit_of(key[k], shift)];
+                    dk[q] = key[k];
+                    dv[q] = val[k];
+                }
+            }
+            __syncthreads();
+        }
+        // the next pass reads what other threads of this block just wrote (and, for `a`, what this block read
+        // before): write back, then drop this CU's cached lines
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
 // ---- reference-structured kernels (kernel-level parity only; one wave per block) ----
 // radix.cl:48-102 block_sort: stable sort of each block of `block` elements by the digit,
 // in place, + digit-major histogram.  Dynamic LDS: keys, values, 2^bits counters.
@@ -515,6 +675,33 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
     return key_bytes == 4
                ? launch_scatter<uint32_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets)
                : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets);
+}
+
+// MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs
+// sorted with the 1024-pair tile.  The histogram of the bucket digit (bits 22..29, digit-major, one row
+// entry per 1024-pair tile) must already be at the start of `scratch` (col_morton_tile writes it).
+// Same result as col_radix_sort.  *oversize (device-visible, may be NULL) receives the size of a bucket
+// that did not fit LDS, if any.
+int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
+                       uint64_t n, void *scratch, uint32_t *oversize) {
+    if (n == 0) return COL_OK;
+    if (!scratch || !vals || !vals_out) return COL_EINVAL;
+    if (tile_for(n, 4) != (u32)(NT_SMALL * IT_SMALL)) return COL_EINVAL;
+    hipStream_t s = col_stream(stream);
+    const size_t nb = tiles_of(n, 4);
+    char *p = (char *)scratch;
+    u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
+    void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
+    u32 *tmp_keys = (u32 *)p;          p += align256((size_t)n * 4);
+    u32 *tmp_vals = (u32 *)p;
+    int rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);
+    if (rc) return rc;
+    k_scatter<u32, 4, IT_SMALL, NT_SMALL><<<dim3((unsigned)nb), dim3(NT_SMALL), 0, s>>>(keys, tmp_keys, vals, tmp_vals, n, (u32)nb,
+                                                                                      BS_SHIFT, hist, g_radix_dbg);
+    COL_LAUNCH_OK();
+    k_bucket_sort<<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+    COL_LAUNCH_OK();
+    return COL_OK;
 }
 
 int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,

@@ -192,6 +192,20 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
                 col_node *nodes, void *bounds, uint32_t *flags, void *scratch,
                 uint32_t *counter, uint32_t *pairs, uint32_t capacity);
 
+/* col_collide with a choice of sort for inputs below 1 Mi spheres (above, the plan is ignored):
+ *   COL_SORT_LSD  the four-pass LSD sort (what col_collide uses);
+ *   COL_SORT_MSD  one global pass on the top 8 code bits, then every bucket finished inside one workgroup's
+ *                 LDS -- 6 launches less.  Same outputs.  A bucket of more than 8192 pairs (clustered scenes)
+ *                 is still sorted correctly but slowly, and its size is stored to *oversize (memory the
+ *                 device can write, e.g. from col_host_alloc; may be NULL): the caller should then go back to
+ *                 COL_SORT_LSD.  collision_amd.collision.Collider does that on its own. */
+#define COL_SORT_LSD 0
+#define COL_SORT_MSD 1
+int col_collide_plan(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded_size,
+                     int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
+                     col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,
+                     uint32_t *collisions, uint32_t capacity, int sort_plan, uint32_t *oversize);
+
 /* ---------------------------------------------------------------- multi-GPU helpers
  * New work (the reference is single-device): device side of the sphere
  * repartition / halo exchange / ghost queries driven by collision_amd/multi.py over RCCL.

@@ -28,11 +28,13 @@ def clustered_scene(n, sigma, r, dtype, seed=4):
     return pts.astype(dtype), np.full(n, r, dtype=dtype)
 
 
-def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=8, capacity=None):
+def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=8, capacity=None, sort_plan=None):
     ctx, cq = hip_env
     dt = coords.dtype
     n = len(coords)
     collider = Collider(ctx, n, ngroups, group_size, dt)
+    if sort_plan is not None:
+        collider.sort_plan = sort_plan
     first_cap = capacity if capacity is not None else max(64 * n, min(n * (n - 1) // 2, 1 << 22))
     ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=first_cap)
     if capacity is None and ref["count"] > first_cap:          # dense scene: the oracle's list was cut short
@@ -230,3 +232,39 @@ def test_three_million_spheres_match_oracle(oracle, hip_env):
     radii = np.full(n, 0.0007, dtype="float32")
     _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256, ngroups=64, capacity=1 << 21)
     assert abs(count - n * n / 2 * (4 * 0.0007) ** 3) < 0.05 * count          # ~99 k pairs
+
+
+@pytest.mark.parametrize("plan", ["lsd", "msd"])
+@pytest.mark.parametrize("kind,n", [("uniform", 1000), ("uniform", 200000), ("uniform", 1000000), ("clustered", 150000),
+                                    ("identical", 20000)])
+def test_both_sort_plans_give_the_oracle_bits(oracle, hip_env, plan, kind, n):
+    """Below 1 Mi spheres col_collide_plan has two sorts (four LSD passes, or one MSD pass + a bucket
+    finish in LDS); clustered and identical centres put more than 8192 codes into one bucket, which the
+    MSD plan must still sort exactly (its slow path)."""
+    if kind == "uniform":
+        coords, radii = uniform_scene(n, 0.1 * n ** (-1.0 / 3.0), "float32")
+    elif kind == "clustered":
+        coords, radii = clustered_scene(n, 0.004, 0.0004, "float32")
+    else:
+        coords = np.full((n, 3), 0.25, dtype="float32")
+        coords[: n // 2] = 0.75
+        radii = np.zeros(n, dtype="float32")                  # empty boxes never overlap each other ...
+        radii[::1000] = 0.3                                   # ... a few big ones find everybody (400 k pairs)
+    check_against_oracle(oracle, hip_env, coords, radii, group_size=128, ngroups=16, sort_plan=plan)
+
+
+def test_auto_plan_falls_back_after_an_oversize_bucket(oracle, hip_env):
+    """The Collider starts on the MSD plan; a clustered scene overflows a bucket, the kernel says so in the
+    pinned word, and the following calls use the LSD plan (and stay exact throughout)."""
+    ctx, cq = hip_env
+    n = 120000
+    coords, radii = clustered_scene(n, 0.003, 0.0003, "float32")
+    collider = Collider(ctx, n, 8, 64, np.dtype("float32"))
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=1 << 24)
+    for _ in range(4):
+        count, pairs = run_collider(ctx, cq, collider, coords, radii, ref["count"])
+        assert count == ref["count"] and pair_set(pairs) == pair_set(ref["pairs"])
+        st = collider_state(cq, collider)
+        np.testing.assert_array_equal(st["codes"], ref["codes"])
+        np.testing.assert_array_equal(st["ids"], ref["ids"])
+    assert collider._lsd_calls_left > 0                        # it has switched

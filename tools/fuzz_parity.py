@@ -70,7 +70,8 @@ while time.time() < t_end:
     if scenes >= first:
       t0 = time.time()
       try:
-        _, _, count, _ = check_against_oracle(oracle_mod, env, coords, radii, group_size=gs, ngroups=int(rng.randint(1, 65)))
+        _, _, count, _ = check_against_oracle(oracle_mod, env, coords, radii, group_size=gs, ngroups=int(rng.randint(1, 65)),
+                                              sort_plan=("lsd", "msd")[scenes % 2])
       except AssertionError:
         from collision_amd.collision import Collider
         from tests.util import run_collider
