@@ -337,17 +337,17 @@ struct BucketLds {
 };
 
 // One stable pass over the (up to BS_CAP) pairs held lane-striped in registers: position of item k of
-// this thread = w * BS_ROW + k * 64 + lane; rows at or beyond `m` hold pads (key 0xFFFFFFFF) and are
-// skipped.  On return pos[k] = rank of the item inside its (wave, digit) group and lds.cnt[i][d] = number
+// this thread = w * row_len + k * 64 + lane (k * 64 < row_len); rows at or beyond `m` hold pads (key
+// 0xFFFFFFFF) and are skipped.  On return pos[k] = rank of the item inside its (wave, digit) group and lds.cnt[i][d] = number
 // of ranked items (pads of a partly valid row included) of wave i with digit d.
 __device__ __forceinline__ void bucket_rank(BucketLds &lds, const u32 (&key)[BS_IT], u32 (&pos)[BS_IT], u32 m, int shift,
-                                            u32 w, u32 tid) {
+                                            u32 w, u32 tid, u32 row_len) {
     for (u32 i = tid; i < BS_NW * RDIG; i += BS_NT) (&lds.cnt[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < BS_IT; k++) {
         pos[k] = 0;
-        if (w * BS_ROW + k * COL_WAVE >= m) continue;            // wave-uniform: a row of pads only
+        if ((u32)k * COL_WAVE >= row_len || w * row_len + k * COL_WAVE >= m) continue;    // wave-uniform: no such row / pads only
         const u32 d = digit_of(key[k], shift);
         const u64 peers = match8(d);
         const u32 below = mbcnt(peers);
@@ -371,14 +371,17 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
     u32 key[BS_IT], val[BS_IT], pos[BS_IT];
 
     if (S <= BS_CAP) {
+        // every wave takes an equal contiguous slice of the bucket (a multiple of 64 positions)
+        const u32 L = ((S + BS_NW - 1) / BS_NW + COL_WAVE - 1) & ~(u32)(COL_WAVE - 1);
 #pragma unroll
         for (int k = 0; k < BS_IT; k++) {
-            const u32 p = w * BS_ROW + k * COL_WAVE + lane;
-            key[k] = p < S ? k_a[start + p] : 0xFFFFFFFFu;
-            val[k] = p < S ? v_a[start + p] : 0u;
+            const u32 p = w * L + k * COL_WAVE + lane;
+            const bool ok = (u32)k * COL_WAVE < L && p < S;
+            key[k] = ok ? k_a[start + p] : 0xFFFFFFFFu;
+            val[k] = ok ? v_a[start + p] : 0u;
         }
         for (int shift = 0; shift < BS_SHIFT; shift += 8) {
-            bucket_rank(lds, key, pos, S, shift, w, tid);
+            bucket_rank(lds, key, pos, S, shift, w, tid, L);
             {   // exclusive over (digit, wave): digit `tid`
                 u32 c[BS_NW], tot = 0;
                 if (tid < RDIG) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < BS_IT; k++) {
-                if (w * BS_ROW + k * COL_WAVE >= S) continue;
+                if ((u32)k * COL_WAVE >= L || w * L + k * COL_WAVE >= S) continue;
                 const u32 q = pos[k] + lds.cnt[w][digit_of(key[k], shift)];
                 lds.keys[q] = key[k];
                 lds.vals[q] = val[k];
@@ -404,16 +407,16 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < BS_IT; k++) {
-                const u32 p = w * BS_ROW + k * COL_WAVE + lane;
-                if (w * BS_ROW + k * COL_WAVE >= S) continue;
-                key[k] = p < S ? lds.keys[p] : 0xFFFFFFFFu;       // pads of the last row sorted last: drop them again
+                const u32 p = w * L + k * COL_WAVE + lane;
+                if ((u32)k * COL_WAVE >= L || w * L + k * COL_WAVE >= S) continue;
+                key[k] = p < S ? lds.keys[p] : 0xFFFFFFFFu;       // pads of a partly valid row sorted last: drop them again
                 val[k] = p < S ? lds.vals[p] : 0u;
             }
         }
 #pragma unroll
         for (int k = 0; k < BS_IT; k++) {
-            const u32 p = w * BS_ROW + k * COL_WAVE + lane;
-            if (p < S) { k_b[start + p] = key[k]; v_b[start + p] = val[k]; }
+            const u32 p = w * L + k * COL_WAVE + lane;
+            if ((u32)k * COL_WAVE < L && p < S) { k_b[start + p] = key[k]; v_b[start + p] = val[k]; }
         }
         return;
     }
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
                 key[k] = p < m ? sk[c0 + p] : 0xFFFFFFFFu;
                 val[k] = p < m ? sv[c0 + p] : 0u;
             }
-            bucket_rank(lds, key, pos, m, shift, w, tid);
+            bucket_rank(lds, key, pos, m, shift, w, tid, (u32)BS_ROW);
             if (tid < RDIG) {
                 // this chunk's (wave, digit) groups start where the digit's running offset stands; pads (digit
                 // 255 in every pass, ranked after the real items of their row) do not advance it
