@@ -10,6 +10,10 @@
 // Histogram layout is the reference's: digit-major, hist[d * nblocks + b], so one flat
 // exclusive scan yields every block's global offset per digit (radix.cl:99-100,127-136).
 //
+// col_radix_sort_msd (col_collide's second plan for small inputs of 30-bit Morton codes): one such
+// global pass on the TOP 8 code bits, then k_bucket_sort finishes each of the 256 buckets in one
+// workgroup's LDS -- see the comment above k_bucket_sort.
+//
 // k_scatter ranking (wave64): each wave owns a contiguous 64*IT slice of the tile and reads
 // it lane-striped, so (wave, item, lane) order == memory order and stability is positional.
 // For an item, the lanes holding the same digit are found with 8 __ballot()s ("match-any"),
