@@ -63,11 +63,14 @@ class Collider:
         # Sort plan for inputs below 1 Mi spheres (include/collision_hip.h, col_collide_plan): the MSD sort
         # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
-        # then take the LSD sort, and the MSD one is tried again every PLAN_RETRY calls.  No host sync: the
+        # then take the LSD sort, and the MSD one is tried again after PLAN_RETRY calls (doubling up to
+        # PLAN_RETRY_MAX while it keeps failing).  No host sync: the
         # word is read when the next call is made.  sort_plan = "lsd" / "msd" pins the choice.
         self.sort_plan = "auto"
         self._plan_word = None
         self._lsd_calls_left = 0
+        self._retry_after = self.PLAN_RETRY
+        self._tried_msd = False
 
     # -- sizes -----------------------------------------------------------------
     @property
@@ -129,7 +132,7 @@ class Collider:
             self._choose_sort_plan(), self._plan_word)
         return hip.Event(cq)
 
-    PLAN_RETRY = 64
+    PLAN_RETRY, PLAN_RETRY_MAX = 64, 4096
 
     def _choose_sort_plan(self):
         """0 = LSD, 1 = MSD (see __init__)."""
@@ -143,10 +146,15 @@ class Collider:
         flag = C.c_uint32.from_address(self._plan_word)
         if flag.value:                               # an earlier call met a bucket that did not fit
             flag.value = 0
-            self._lsd_calls_left = self.PLAN_RETRY
+            self._lsd_calls_left = self._retry_after
+            self._retry_after = min(2 * self._retry_after, self.PLAN_RETRY_MAX)      # back off while it keeps failing
+            self._tried_msd = False
+        elif self._tried_msd and not self._lsd_calls_left:
+            self._retry_after = self.PLAN_RETRY      # the MSD plan went through: forget the back-off
         if self._lsd_calls_left:
             self._lsd_calls_left -= 1
             return 0
+        self._tried_msd = True
         return 1
 
     def __del__(self):
