@@ -129,3 +129,37 @@ def _production_pass(hip_env, key_dtype, val_bytes, n):
         np.testing.assert_array_equal(download(cq, out_k, key_dtype), keys[order])
         if val_bytes:
             np.testing.assert_array_equal(download(cq, out_v, np.uint8, vals.shape), vals[order])
+
+
+@pytest.mark.parametrize("big", [1, 63, 64, 65, 4095, 8191, 8192, 8193, 20000, 70000])
+def test_msd_sort_bucket_sizes(hip_env, big):
+    """col_radix_sort_msd (col_collide's second sort plan): one bucket of exactly `big` codes next to
+    ordinary ones and the 0xFFFFFFFF pads -- up to 8192 a bucket is finished in LDS, above it goes
+    through the chunked global path and is reported in *oversize.  Result = stable sort on all 32 bits."""
+    ctx, cq = hip_env
+    rs = np.random.RandomState(big)
+    n_real, pads = 300000 + big, 777
+    low = rs.randint(0, 1 << 22, size=n_real, dtype=np.uint64)
+    low[::5] = low[1]                                              # duplicates: stability matters
+    digit = rs.randint(0, 256, size=n_real).astype(np.uint64)
+    digit[digit == 5] = 6
+    digit[rs.choice(n_real, size=big, replace=False)] = 5          # bucket 5 holds exactly `big` codes
+    keys = np.concatenate([((digit << np.uint64(22)) | low).astype(np.uint32), np.full(pads, 0xFFFFFFFF, np.uint32)])
+    n = len(keys)
+    vals = np.arange(n, dtype=np.uint32)
+    tile = call.col_radix_tile(n, 4, 4)
+    assert tile == 1024
+    nb = -(-n // tile)
+    d8 = ((keys >> np.uint32(22)) & np.uint32(255)).astype(np.int64)
+    hist = np.zeros((256, nb), np.uint32)
+    np.add.at(hist, (d8, np.arange(n) // tile), 1)
+    scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+    kb, vb = upload(ctx, keys), upload(ctx, vals)
+    ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+    flag = upload(ctx, np.zeros(1, np.uint32))
+    hip.write_buffer(cq, scratch, hist)                            # the bucket-digit histogram col_morton_tile would leave
+    call.col_radix_sort_msd(cq.stream, kb.ptr, ko.ptr, vb.ptr, vo.ptr, n, scratch.ptr, flag.ptr)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
+    np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
+    assert int(download(cq, flag, np.uint32, 1)[0]) == (big if big > 8192 else 0)
