@@ -70,7 +70,6 @@ _PROTOS = {
     "col_lbvh": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_uint32, C.c_int]),
     "col_collide_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
-    # internal (csrc/col_common.h), bound for the kernel-level tests only
     "col_radix_sort_msd": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                   C.c_void_p]),
     "col_collide_plan": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,

@@ -40,8 +40,6 @@ extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, in
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
                                uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks, int hist_shift);
-extern "C" int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
-                                  uint32_t *vals_out, uint64_t n, void *scratch, uint32_t *oversize);
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 
