@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 // replaces three global passes of three launches each.  A larger bucket (clustered codes) takes the
 // same three passes through global memory, chunk by chunk, by its one block: correct but slow, and
 // reported through *oversize so that the caller goes back to the LSD sort.
-constexpr int BS_NT = 512, BS_IT = 16, BS_NW = BS_NT / COL_WAVE;
+constexpr int BS_NT = 1024, BS_IT = 8, BS_NW = BS_NT / COL_WAVE;
 constexpr u32 BS_CAP = BS_NT * BS_IT;          // 8192 pairs
 constexpr int BS_SHIFT = 22;                   // bucket digit = bits 22..29 of a 30-bit Morton code (pads: 255)
 constexpr int BS_ROW = COL_WAVE * BS_IT;       // positions per wave
