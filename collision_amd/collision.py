@@ -65,7 +65,8 @@ class Collider:
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
         # then take the LSD sort, and the MSD one is tried again after PLAN_RETRY calls (doubling up to
         # PLAN_RETRY_MAX while it keeps failing).  No host sync: the
-        # word is read when the next call is made.  sort_plan = "lsd" / "msd" pins the choice.
+        # word is read when the next call is made.  sort_plan = "lsd" / "msd" pins the choice (a captured
+        # hipGraph replays whichever plan the captured call chose: pin "lsd" for clustered scenes).
         self.sort_plan = "auto"
         self._plan_word = None
         self._lsd_calls_left = 0
