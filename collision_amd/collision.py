@@ -92,7 +92,6 @@ class Collider:
             "codes0": self.padded_size * 4, "codes1": self.padded_size * 4,
             "nodes": self.n_nodes * Node.itemsize,
             "bounds": self.n_nodes * 2 * 4 * coord_bytes,     # also carries the traversal links
-            "flags": self.n_nodes * 4,
             "scratch": call.col_collide_scratch_bytes(self.size, self.padded_size, coord_bytes),
         }
         for name, nbytes in want.items():
@@ -101,7 +100,16 @@ class Collider:
         a = self._alloc
         self._ids_bufs = [a["ids0"], a["ids1"]]
         self._codes_bufs = [a["codes0"], a["codes1"]]
-        self._nodes_buf, self._bounds_buf, self._flags_buf = a["nodes"], a["bounds"], a["flags"]
+        self._nodes_buf, self._bounds_buf = a["nodes"], a["bounds"]
+
+    @property
+    def _flags_buf(self):
+        """Arrival counters of the reference's internalBounds (collision.py:147-150): the fused refit
+        (csrc/lbvh.hip) does not use them, so they are only allocated if somebody asks (col_bvh_refit)."""
+        nbytes = self.n_nodes * 4
+        if "flags" not in self._alloc or self._alloc["flags"].size != nbytes:
+            self._alloc["flags"] = hip.Buffer(self.program.context, nbytes)
+        return self._alloc["flags"]
 
     def resize(self, size=None, ngroups=None, group_size=None, radix_bits=None):
         if size is not None:
@@ -128,7 +136,7 @@ class Collider:
             cq.stream, coords_buf.ptr, radii_buf.ptr, self.size, self.padded_size,
             self.program.coord_dtype.itemsize,
             self._codes_bufs[0].ptr, self._codes_bufs[1].ptr, self._ids_bufs[0].ptr, self._ids_bufs[1].ptr,
-            self._nodes_buf.ptr, self._bounds_buf.ptr, self._flags_buf.ptr, self._alloc["scratch"].ptr,
+            self._nodes_buf.ptr, self._bounds_buf.ptr, None, self._alloc["scratch"].ptr,
             n_collisions_buf.ptr, None if collisions_buf is None else collisions_buf.ptr, n_collisions,
             self._choose_sort_plan(), self._plan_word)
         return hip.Event(cq)

@@ -588,6 +588,8 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
+    // a forced radix tile class (diagnostics) would not match the histogram the fused Morton kernel writes
+    if (col_radix_tile_override_active()) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
     if (n == 0) {
         COL_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), s));             // collision.py:151-154

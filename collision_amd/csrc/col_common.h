@@ -43,6 +43,8 @@ extern "C" int col_morton_tile(void *stream, const void *coords, const void *rad
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 
+extern "C" int col_radix_tile_override_active(void);      // diagnostics: col_debug_radix_tile() is in force
+
 static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }
 
 static inline uint64_t col_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

@@ -23,6 +23,7 @@
 // tile-sorted position and streamed out so that consecutive lanes write consecutive
 // addresses inside each digit run.
 #include "col_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -48,10 +49,18 @@ template <> struct Val<32> { typedef V32 T; };
 
 template <typename K> __device__ __forceinline__ u32 digit_of(K key, int shift) { return (u32)(key >> shift) & (RDIG - 1); }
 
-// diagnostics (col_debug_radix mode 32): cycles per phase of k_scatter, summed over blocks
+// Diagnostics live in their own template instances (DIAG = true), selected by col_debug_radix(mode != 0):
+// the production instances take no mode argument and carry none of the branches below.
+// (mode 32: cycles per phase of k_scatter, summed over blocks)
 __device__ unsigned long long g_stamp[8];
+struct DiagOff {};
+struct DiagOn { int mode; };
+template <bool DIAG> struct DiagArg { typedef DiagOff T; };
+template <> struct DiagArg<true> { typedef DiagOn T; };
+__device__ __forceinline__ constexpr int diag_mode(DiagOff) { return 0; }
+__device__ __forceinline__ int diag_mode(DiagOn d) { return d.mode; }
 #define STAMP(slot)                                                              \
-    if ((dbg & 32) && threadIdx.x == 0) {                                        \
+    if (DIAG && (dbg & 32) && threadIdx.x == 0) {                                \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
         atomicAdd(&g_stamp[slot], t_ - t_prev);                                  \
         t_prev = t_;                                                             \
@@ -62,14 +71,25 @@ __device__ unsigned long long g_stamp[8];
 // DIFFER from me in that bit; the eight results are ORed (v_or3) and complemented.  12 VALU per
 // 32-lane half instead of 16 for the and-chain formulation.
 __device__ __forceinline__ u64 match8(u32 d) {
+    // Three batches (masks, ballots, folds) instead of bit by bit: a v_cmp result needs two wait states
+    // before a VALU instruction may read it as an SGPR operand, and seven other compares hide them.
+    u32 m[8];
+    u64 bal[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        m[b] = (u32)__builtin_amdgcn_sbfe(d, b, 1);                         // my bit, replicated
+        // (opaque to the optimiser: it otherwise derives the comparison from d again -- shift + sign test --
+        // instead of comparing the mask it already has: 5 instead of 4 VALU per bit)
+        asm("" : "+v"(m[b]));
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) bal[b] = __builtin_amdgcn_ballot_w64(m[b] != 0);
     u32 dlo = 0, dhi = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const u32 m = (u32)__builtin_amdgcn_sbfe(d, b, 1);                  // my bit, replicated
-        const u64 bal = __builtin_amdgcn_ballot_w64(m != 0);
         // acc | (ballot ^ mine) in one v_bitop3 per half (truth table 0xF6 for (acc, ballot, mine))
-        dlo = __builtin_amdgcn_bitop3_b32(dlo, (u32)bal, m, 0xF6);
-        dhi = __builtin_amdgcn_bitop3_b32(dhi, (u32)(bal >> 32), m, 0xF6);
+        dlo = __builtin_amdgcn_bitop3_b32(dlo, (u32)bal[b], m[b], 0xF6);
+        dhi = __builtin_amdgcn_bitop3_b32(dhi, (u32)(bal[b] >> 32), m[b], 0xF6);
     }
     return ~(((u64)dhi << 32) | dlo);
 }
@@ -127,11 +147,12 @@ template <int SCOPE, typename X> __device__ __forceinline__ void st_scope(X *p, 
 }
 
 // ---- scatter ----
-template <typename K, int VB, int IT, int NT>
+template <typename K, int VB, int IT, int NT, bool DIAG>
 __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
-                                                const u32 *__restrict__ offsets, int dbg) {
+                                                const u32 *__restrict__ offsets, typename DiagArg<DIAG>::T diag) {
+    const int dbg = diag_mode(diag);        // the constant 0 in the production instance
     constexpr int TILE = NT * IT;
     constexpr int NW = NT / COL_WAVE;
     constexpr bool HAS_V = VB > 0;
@@ -158,7 +179,8 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     const uint64_t tile_base = (uint64_t)b * TILE;
     const u32 valid = (u32)min((uint64_t)TILE, n - tile_base);
 
-    unsigned long long t_prev = (dbg & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_prev = (DIAG && (dbg & 32)) ? __builtin_amdgcn_s_memtime() : 0ull;
+    (void)t_prev;
     // this tile's global offset of digit `tid`: one scattered 4-byte load per thread, issued now so that
     // its latency hides under the loads and the ranking instead of sitting between two barriers
     const u32 my_offset = tid < RDIG ? offsets[(uint64_t)tid * nblocks + b] : 0u;
@@ -318,6 +340,207 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     }
     if (dbg & 32) { __builtin_amdgcn_s_waitcnt(0); }
     STAMP(4)      // read back + global stores (issue only)
+}
+
+
+// ---- scatter, big inputs: persistent blocks, LDS-DMA double buffering ----
+// k_scatter above is one tile per workgroup: load (a third of the block's cycles is the wait for HBM),
+// rank, stage, store -- and nothing of the next tile is in flight meanwhile; two such blocks per CU
+// overlap only by chance.  Here ONE 1024-thread workgroup per CU walks its tiles, and the NEXT tile is
+// always on its way into the second LDS buffer:
+//   * loads are LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so nothing for the compiler to
+//     spill or wait on), each wave fetching its own 512-pair slice; the lane-striped order the ranking
+//     needs is then just a strided ds_read of that slice (no ds_write_b128 transposition pass);
+//   * per tile: read slice -> rank -> [B1] digit scan [B2a, B2b] -> write (key, value) PAIRS at their tile-sorted
+//     slot (one ds_write_b64) -> [B3] read back (ds_read_b64) -> [B4] wait for the DMA issued one
+//     tile ago, issue the DMA of the tile after next into the buffer just freed, store this tile;
+//   * barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would drain the stores and the DMA;
+//   * the tile's 256 scanned offsets arrive by LDS-DMA too (one dword per lane, waves 0-3), so the
+//     loop has no VGPR-destination load at all and the only vmcnt wait is the one above, for
+//     operations issued a whole tile earlier.
+// XCD-aware schedule as in k_scatter: every XCD owns a contiguous range of tiles and its workgroups
+// stride through it together, so neighbouring tiles' ~128-byte runs meet in one L2.
+constexpr int PT = 1024, PIT = 8, PNW = PT / COL_WAVE;
+constexpr int PTILE = PT * PIT;                // 8192 pairs, the BIG tile
+constexpr int PROW = COL_WAVE * PIT;           // pairs per wave
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ u32 lds_addr(const void *p) {
+    return (u32)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// one LDS-DMA: lane l moves 16 (4) bytes from its own global address to lds_base + 16 (4) * l
+__device__ __forceinline__ void glds16(const void *gsrc, u32 lds_base) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, u32 lds_base) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+template <bool HAS_V> struct ScatterPLds {
+    static constexpr int BUFW = HAS_V ? 2 * PTILE : PTILE;      // dwords per buffer: keys, then values
+    __attribute__((aligned(16))) u32 buf[2][BUFW];
+    u32 cnt[PNW][RDIG];                                         // wave-private digit counters
+    u32 raw[2][RDIG];                                           // the tile's scanned offsets, as fetched
+    u32 goff[RDIG];
+    u32 ws[RDIG / COL_WAVE];
+};
+
+// One tile of k_scatter_p from "my slice is in registers" to "sorted pairs and their global slots are in
+// registers": rank, digit scan, stage through `buf` (in place of the slices), read back.
+template <bool HAS_V, int VAR>
+__device__ __forceinline__ void scatter_p_tile(ScatterPLds<HAS_V> &L, u32 *buf, const u32 *raw, const u32 (&key)[PIT],
+                                               const u32 (&val)[HAS_V ? PIT : 1], int shift, u32 tile_base, u32 tid, u32 lane,
+                                               u32 w, u32 (&okey)[PIT], u32 (&oval)[HAS_V ? PIT : 1], u32 (&g)[PIT]) {
+    // rank inside (wave, digit): wave-private counters, program order keeps them consistent
+    u32 pos[PIT];
+#pragma unroll
+    for (int k = 0; k < PIT; k++) {
+        const u32 d = digit_of(key[k], shift);
+        const u64 peers = match8(d);
+        const u32 below = mbcnt(peers);
+        const u32 prev = L.cnt[w][d];
+        if (below == 0) L.cnt[w][d] = prev + (u32)__popcll(peers);
+        pos[k] = prev + below;
+    }
+    lds_barrier();                                                            // B1: counters complete, slices read
+
+    // digit `tid` (waves 0-3): exclusive over waves, then over digits
+    u32 c[PNW], tot = 0, incl = 0;
+    if (tid < RDIG) {
+#pragma unroll
+        for (int i = 0; i < PNW; i++) { c[i] = L.cnt[i][tid]; tot += c[i]; }
+        incl = wave_incl_scan(tot);
+        if (lane == COL_WAVE - 1) L.ws[w] = incl;
+    }
+    lds_barrier();                                                            // B2a
+    if (tid < RDIG) {
+        u32 run = incl - tot;
+#pragma unroll
+        for (int i = 0; i < RDIG / COL_WAVE; i++) run += ((u32)i < w ? L.ws[i] : 0u);
+        L.goff[tid] = raw[tid] - run;       // global position of tile-sorted slot i with digit d is goff[d] + i
+#pragma unroll
+        for (int i = 0; i < PNW; i++) { L.cnt[i][tid] = run; run += c[i]; }
+    }
+    lds_barrier();                                                            // B2b
+
+    // (key, value) PAIRS to their tile-sorted slot: one ds_write_b64 per item
+#pragma unroll
+    for (int k = 0; k < PIT; k++) {
+        const u32 p = pos[k] + L.cnt[w][digit_of(key[k], shift)];
+        if (HAS_V) reinterpret_cast<uint2 *>(buf)[p] = make_uint2(key[k], val[k]);
+        else buf[p] = key[k];
+    }
+    lds_barrier();                                                            // B3
+
+#pragma unroll
+    for (int k = 0; k < PIT; k++) {
+        const u32 i = k * PT + tid;
+        if (HAS_V) {
+            const uint2 kv = reinterpret_cast<const uint2 *>(buf)[i];
+            okey[k] = kv.x; oval[k] = kv.y;
+        } else okey[k] = buf[i];
+        g[k] = L.goff[digit_of(okey[k], shift)] + i;
+        if (VAR & 1) g[k] = tile_base + i;                                   // timing ablation: coalesced output
+    }
+    for (u32 i = lane; i < RDIG; i += COL_WAVE) L.cnt[w][i] = 0;            // for the next tile (wave-private)
+    lds_barrier();                                                            // B4: `buf` is free again
+}
+
+// VAR (timing ablations, col_debug_radix): bit 0 = coalesced output, bit 1 = wait for everything (stores
+// too) before the next DMA instead of the counted wait.
+template <bool HAS_V, int VAR>
+__global__ __launch_bounds__(PT) void k_scatter_p(const u32 *__restrict__ keys_in, u32 *__restrict__ keys_out,
+                                                  const u32 *__restrict__ vals_in, u32 *__restrict__ vals_out,
+                                                  uint64_t n, u32 nblocks, int shift, const u32 *__restrict__ offsets) {
+    __shared__ ScatterPLds<HAS_V> L;
+    const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1);
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid / COL_WAVE));
+
+    // this workgroup's tiles: first, first + step, ... < end
+    u32 first, step, end;
+    if (gridDim.x >= 8) {
+        const u32 q = nblocks / 8, r = nblocks % 8, xcd = blockIdx.x % 8;
+        const u32 lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        first = lo + blockIdx.x / 8;
+        step = (gridDim.x + 7 - xcd) / 8;
+        end = lo + q + (xcd < r ? 1u : 0u);
+    } else {
+        first = blockIdx.x; step = gridDim.x; end = nblocks;
+    }
+    // The pipelined loop takes FULL tiles only (it has no VGPR-destination load, so hipcc places no vmcnt
+    // wait in it); the ragged last tile of the input, if this workgroup owns it, follows the loop.
+    const u32 n_full = (u32)(n / PTILE);
+    const u32 end_full = end < n_full ? end : n_full;
+
+    // DMA of a full `tile` into buffer `sel`: this wave's slice of the keys (and values), plus (waves 0-3)
+    // 64 of the tile's 256 scanned offsets
+    auto issue = [&](u32 tile, u32 sel) {
+        if (tile >= end_full) return;
+        const uint64_t base = (uint64_t)tile * PTILE + w * PROW;
+#pragma unroll
+        for (int j = 0; j < PROW / 256; j++) {
+            glds16(keys_in + base + j * 256 + lane * 4, lds_addr(&L.buf[sel][w * PROW + j * 256]));
+            if (HAS_V) glds16(vals_in + base + j * 256 + lane * 4, lds_addr(&L.buf[sel][PTILE + w * PROW + j * 256]));
+        }
+        if (w < RDIG / COL_WAVE) glds4(offsets + (uint64_t)tid * nblocks + tile, lds_addr(&L.raw[sel][w * COL_WAVE]));
+    };
+
+    for (u32 i = lane; i < RDIG; i += COL_WAVE) L.cnt[w][i] = 0;
+    issue(first, 0);
+    issue(first + step, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    u32 sel = 0;
+    for (u32 tile = first; tile < end_full; tile += step, sel ^= 1) {
+        u32 *buf = L.buf[sel];
+        // my slice, lane-striped: (wave, item, lane) order == memory order, stability is positional
+        u32 key[PIT], val[HAS_V ? PIT : 1], okey[PIT], oval[HAS_V ? PIT : 1], g[PIT];
+#pragma unroll
+        for (int k = 0; k < PIT; k++) key[k] = buf[w * PROW + k * COL_WAVE + lane];
+        if (HAS_V) {
+#pragma unroll
+            for (int k = 0; k < PIT; k++) val[k] = buf[PTILE + w * PROW + k * COL_WAVE + lane];
+        }
+        scatter_p_tile<HAS_V, VAR>(L, buf, L.raw[sel], key, val, shift, tile * (u32)PTILE, tid, lane, w, okey, oval, g);
+        // The DMA of the next tile and the stores of the previous one were issued a whole tile ago, in that
+        // order: waiting for all but the youngest 2 * PIT (the stores) operations waits for the DMA only.
+        if (VAR & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HAS_V ? 2 * PIT : PIT) : "memory");
+        issue(tile + 2 * step, sel);
+#pragma unroll
+        for (int k = 0; k < PIT; k++) {
+            keys_out[g[k]] = okey[k];
+            if (HAS_V) vals_out[g[k]] = oval[k];
+        }
+    }
+
+    if (end == nblocks && n_full < nblocks && (nblocks - 1 - first) % step == 0 && nblocks - 1 >= first) {
+        // the ragged last tile: loaded synchronously; pads sort last (positional stability) and are never stored
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32 tile = nblocks - 1;
+        const uint64_t tile_base = (uint64_t)tile * PTILE;
+        const u32 valid = (u32)(n - tile_base);
+        u32 key[PIT], val[HAS_V ? PIT : 1], okey[PIT], oval[HAS_V ? PIT : 1], g[PIT];
+#pragma unroll
+        for (int k = 0; k < PIT; k++) {
+            const u32 li = w * PROW + k * COL_WAVE + lane;
+            key[k] = li < valid ? keys_in[tile_base + li] : 0xFFFFFFFFu;
+            if (HAS_V) val[k] = li < valid ? vals_in[tile_base + li] : 0u;
+        }
+        if (tid < RDIG) L.raw[0][tid] = offsets[(uint64_t)tid * nblocks + tile];     // read back by the same thread
+        scatter_p_tile<HAS_V, VAR>(L, L.buf[0], L.raw[0], key, val, shift, (u32)tile_base, tid, lane, w, okey, oval, g);
+#pragma unroll
+        for (int k = 0; k < PIT; k++) {
+            if ((u32)k * PT + tid < valid) {
+                keys_out[g[k]] = okey[k];
+                if (HAS_V) vals_out[g[k]] = oval[k];
+            }
+        }
+    }
 }
 
 // ---- MSD finish: one block sorts one top-digit bucket on its remaining low bits ----
@@ -566,16 +789,37 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
     }
 }
 
+// Process-wide diagnostics switches (col_debug_radix / col_debug_radix_tile): they change the kernels of
+// EVERY caller in the process and are not synchronised -- set them from one thread, with no sort in flight.
 int g_radix_dbg = 0;
+int g_radix_tile_override = 0;      // 0 = automatic, else 1024 / 4096 / 8192
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-int g_radix_tile_override = 0;      // diagnostics (col_debug_radix_tile): 0 = automatic, else 1024 / 4096 / 8192
-inline u32 tile_for(uint64_t n, int key_bytes) {
+inline u32 tile_auto(uint64_t n, int key_bytes) {
     u32 t = n < SMALL_N ? (u32)(NT_SMALL * IT_SMALL) : n < BIG_N ? (u32)(NT_MID * IT_BIG) : (u32)(NT_BIG * IT_BIG);
-    if (g_radix_tile_override) t = (u32)g_radix_tile_override;
+    if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
+    return t;
+}
+inline u32 tile_for(uint64_t n, int key_bytes) {
+    if (!g_radix_tile_override) return tile_auto(n, key_bytes);
+    u32 t = (u32)g_radix_tile_override;
     if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
     return t;
 }
 inline u32 tiles_of(uint64_t n, int key_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes)); }
+// The most tiles any n' <= n can have: the tile GROWS with n, so a smaller input may have more tiles (and a
+// larger histogram) than n itself.  Scratch is sized with this bound, so one scratch buffer sized for n
+// serves every n' <= n (col_collide on a varying number of owned spheres: collision_amd/multi.py).
+inline size_t max_tiles_upto(uint64_t n, int key_bytes) {
+    if (n == 0) return 1;
+    size_t m = col_ceil_div(n < SMALL_N ? n : SMALL_N - 1, NT_SMALL * IT_SMALL);
+    if (n >= SMALL_N) {
+        const uint64_t top = (key_bytes == 8 || n < BIG_N) ? n : BIG_N - 1;
+        m = std::max(m, (size_t)col_ceil_div(top, NT_MID * IT_BIG));
+    }
+    if (n >= BIG_N && key_bytes != 8) m = std::max(m, (size_t)col_ceil_div(n, NT_BIG * IT_BIG));
+    if (g_radix_tile_override) m = std::max(m, (size_t)col_ceil_div(n, NT_SMALL * IT_SMALL));
+    return m;
+}
 
 inline u32 hist_group(u32 nblocks) {
     // keep >= ~1024 histogram blocks when the input allows, else fewer tiles per block
@@ -597,24 +841,54 @@ int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist
     return COL_OK;
 }
 
+template <typename K, int VB, int IT, int NT>
+int launch_scatter_one(hipStream_t s, const K *ki, K *ko, const void *vals, void *vals_out, uint64_t n, u32 nb, int shift,
+                       const u32 *offsets) {
+    dim3 grid(nb), block(NT);
+    // the diagnostics instances exist for the profiled combinations only (u32 keys, no / 4-byte values)
+    if constexpr (sizeof(K) == 4 && (VB == 0 || VB == 4)) {
+        if (g_radix_dbg) {
+            // timing ablation: unused dynamic LDS lowers the number of resident blocks per CU (modes 512 / 1024)
+            const size_t dyn = (g_radix_dbg & 1024) ? 18432 : (g_radix_dbg & 512) ? 4608 : 0;
+            k_scatter<K, VB, IT, NT, true><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, DiagOn{g_radix_dbg});
+            COL_LAUNCH_OK();
+            return COL_OK;
+        }
+    }
+    k_scatter<K, VB, IT, NT, false><<<grid, block, 0, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, DiagOff{});
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
 template <typename K, int IT, int NT>
 int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
-                      uint64_t n, int vb, int pass, const u32 *offsets) {
-    const u32 nb = tiles_of(n, (int)sizeof(K));
-    dim3 grid(nb), block(NT);
+                      uint64_t n, int vb, int shift, const u32 *offsets) {
+    const u32 nb = (u32)col_ceil_div(n, NT * IT);
     const K *ki = (const K *)keys;
     K *ko = (K *)keys_out;
-    const int shift = pass * 8;
     if (!vals || !vals_out) vb = 0;
-    // timing ablation: unused dynamic LDS lowers the number of resident blocks per CU (modes 512 / 1024)
-    const size_t dyn = (g_radix_dbg & 1024) ? 18432 : (g_radix_dbg & 512) ? 4608 : 0;
     switch (vb) {
-    case 0: k_scatter<K, 0, IT, NT><<<grid, block, dyn, s>>>(ki, ko, nullptr, nullptr, n, nb, shift, offsets, g_radix_dbg); break;
-    case 4: k_scatter<K, 4, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 8: k_scatter<K, 8, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 16: k_scatter<K, 16, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
-    case 32: k_scatter<K, 32, IT, NT><<<grid, block, dyn, s>>>(ki, ko, vals, vals_out, n, nb, shift, offsets, g_radix_dbg); break;
+    case 0: return launch_scatter_one<K, 0, IT, NT>(s, ki, ko, nullptr, nullptr, n, nb, shift, offsets);
+    case 4: return launch_scatter_one<K, 4, IT, NT>(s, ki, ko, vals, vals_out, n, nb, shift, offsets);
+    case 8: return launch_scatter_one<K, 8, IT, NT>(s, ki, ko, vals, vals_out, n, nb, shift, offsets);
+    case 16: return launch_scatter_one<K, 16, IT, NT>(s, ki, ko, vals, vals_out, n, nb, shift, offsets);
+    case 32: return launch_scatter_one<K, 32, IT, NT>(s, ki, ko, vals, vals_out, n, nb, shift, offsets);
     default: return COL_EINVAL;
+    }
+}
+
+// the persistent LDS-DMA kernel: u32 keys, no or 4-byte values, the BIG tile
+constexpr int P_MAX_BLOCKS = 256;          // one 1024-thread workgroup (147 KB of LDS) per CU
+template <bool HAS_V>
+int launch_scatter_p(hipStream_t s, const u32 *ki, u32 *ko, const u32 *vi, u32 *vo, uint64_t n, int shift, const u32 *offsets) {
+    const u32 nb = (u32)col_ceil_div(n, PTILE);
+    dim3 grid(nb < (u32)P_MAX_BLOCKS ? nb : (u32)P_MAX_BLOCKS), block(PT);
+    const int var = (g_radix_dbg & 2 ? 1 : 0) | (g_radix_dbg & 2048 ? 2 : 0);
+    switch (var) {
+    case 0: k_scatter_p<HAS_V, 0><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
+    case 1: k_scatter_p<HAS_V, 1><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
+    case 2: k_scatter_p<HAS_V, 2><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
+    default: k_scatter_p<HAS_V, 3><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
     }
     COL_LAUNCH_OK();
     return COL_OK;
@@ -622,14 +896,20 @@ int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const voi
 
 template <typename K>
 int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
-                   uint64_t n, int vb, int pass, const u32 *offsets) {
+                   uint64_t n, int vb, int shift, const u32 *offsets) {
     const u32 tile = tile_for(n, (int)sizeof(K));
     if (tile == (u32)(NT_SMALL * IT_SMALL))
-        return launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+        return launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
     if (tile == (u32)(NT_MID * IT_BIG))
-        return launch_scatter_it<K, IT_BIG, NT_MID>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
-    if constexpr (sizeof(K) == 4)
-        return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, pass, offsets);
+        return launch_scatter_it<K, IT_BIG, NT_MID>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
+    if constexpr (sizeof(K) == 4) {
+        const bool has_v = vals && vals_out && vb;
+        if ((!has_v || vb == 4) && !(g_radix_dbg & 4096)) {      // mode 4096: the one-tile-per-workgroup kernel instead
+            if (has_v) return launch_scatter_p<true>(s, (const u32 *)keys, (u32 *)keys_out, (const u32 *)vals, (u32 *)vals_out, n, shift, offsets);
+            return launch_scatter_p<false>(s, (const u32 *)keys, (u32 *)keys_out, nullptr, nullptr, n, shift, offsets);
+        }
+        return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
+    }
     return COL_EINVAL;
 }
 
@@ -660,12 +940,16 @@ int col_debug_radix_stamps(uint64_t *out, int reset) {
 
 uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)val_bytes; return tile_for(n, key_bytes); }
 
+// Monotone in n: sized for the largest histogram any n' <= n can need (see max_tiles_upto), so a scratch
+// buffer sized for n serves every smaller sort / col_collide call as well.
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
-    const size_t nb = tiles_of(n, key_bytes);
-    const size_t hist = align256((size_t)RDIG * (nb ? nb : 1) * sizeof(u32));
+    const size_t nb = max_tiles_upto(n, key_bytes);
+    const size_t hist = align256((size_t)RDIG * nb * sizeof(u32));
     return hist + align256(col_scan_scratch_bytes((uint64_t)RDIG * nb)) + align256((size_t)n * key_bytes) +
            align256((size_t)n * val_bytes) + 256;
 }
+
+int col_radix_tile_override_active(void) { return g_radix_tile_override != 0; }
 
 int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_bytes, int val_bytes, int pass,
                         uint32_t *hist) {
@@ -680,8 +964,8 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
     if (bad_sizes(n, key_bytes, val_bytes) || pass < 0 || pass >= key_bytes) return COL_EINVAL;
     if (n == 0) return COL_OK;
     return key_bytes == 4
-               ? launch_scatter<uint32_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets)
-               : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass, offsets);
+               ? launch_scatter<uint32_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass * 8, offsets)
+               : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass * 8, offsets);
 }
 
 // MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs
@@ -693,9 +977,9 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
                        uint64_t n, void *scratch, uint32_t *oversize) {
     if (n == 0) return COL_OK;
     if (!scratch || !vals || !vals_out) return COL_EINVAL;
-    if (tile_for(n, 4) != (u32)(NT_SMALL * IT_SMALL)) return COL_EINVAL;
+    if (tile_auto(n, 4) != (u32)(NT_SMALL * IT_SMALL)) return COL_EINVAL;      // (a forced tile class does not apply here)
     hipStream_t s = col_stream(stream);
-    const size_t nb = tiles_of(n, 4);
+    const size_t nb = col_ceil_div(n, NT_SMALL * IT_SMALL);
     char *p = (char *)scratch;
     u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
@@ -703,9 +987,8 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
     u32 *tmp_vals = (u32 *)p;
     int rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);
     if (rc) return rc;
-    k_scatter<u32, 4, IT_SMALL, NT_SMALL><<<dim3((unsigned)nb), dim3(NT_SMALL), 0, s>>>(keys, tmp_keys, vals, tmp_vals, n, (u32)nb,
-                                                                                      BS_SHIFT, hist, g_radix_dbg);
-    COL_LAUNCH_OK();
+    rc = launch_scatter_it<u32, IT_SMALL, NT_SMALL>(s, keys, tmp_keys, vals, tmp_vals, n, 4, BS_SHIFT, hist);
+    if (rc) return rc;
     k_bucket_sort<<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
     COL_LAUNCH_OK();
     return COL_OK;

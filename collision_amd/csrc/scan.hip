@@ -9,6 +9,7 @@
 // per-thread totals are scanned with wave shuffles and a 4-entry LDS hand-off between
 // the block's waves (no Blelloch sweeps, no log2(n) barriers).
 #include "col_common.h"
+#include <atomic>
 
 namespace {
 
@@ -77,9 +78,11 @@ __global__ __launch_bounds__(ST) void k_scan_apply(u32 *__restrict__ data, uint6
 // Every block publishes its tile sum as an 8-byte {epoch, sum} granule (one relaxed agent-scope
 // atomic store: the data is the flag, cdna_hip_programming.md guideline 16 R2), then wave 0 reads
 // the granules of all predecessor tiles in parallel (lane = predecessor) and adds them up -- a
-// look-back without a chain, so the depth is two hops whatever the tile count.  All <= 256 blocks
-// are resident at once (one per CU at most), so the polls always complete; the epoch makes stale
-// granules from earlier calls invisible without a memset launch.
+// look-back without a chain, so the depth is two hops whatever the tile count.  Forward progress: a
+// block only waits for blocks with a LOWER index, and the dispatcher starts workgroups in index order,
+// so whichever blocks are resident (other streams or processes may hold part of the GPU) always include
+// one that waits for nothing -- the same assumption every decoupled look-back scan makes.  The epoch
+// makes stale granules from earlier calls invisible without a memset launch.
 constexpr u32 CHAIN_MAX_TILES = 256;      // 4 waves x 64 predecessors
 __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n, u64 *__restrict__ status, u32 epoch) {
     __shared__ u32 ws[ST / COL_WAVE];
@@ -160,8 +163,9 @@ int scan_rec(hipStream_t s, u32 *data, uint64_t n, char *scratch) {
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (nb > 1 && nb <= CHAIN_MAX_TILES) (void)hipStreamIsCapturing(s, &capture);
     if (nb > 1 && nb <= CHAIN_MAX_TILES && capture == hipStreamCaptureStatusNone) {
-        static u32 epoch = 0x5EED0000u;          // never reused within a process; see k_scan_chain
-        epoch++;
+        // never reused within a process (see k_scan_chain); atomic: host threads may drive different streams
+        static std::atomic<u32> epoch_counter{0x5EED0000u};
+        const u32 epoch = epoch_counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
         k_scan_chain<<<dim3((unsigned)nb), dim3(ST), 0, s>>>(data, (u32)n, (u64 *)scratch, epoch);
         COL_LAUNCH_OK();
         return COL_OK;

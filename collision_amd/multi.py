@@ -300,7 +300,7 @@ class HipEngine(ProtocolOps):
             call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
         call.col_collide_plan(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), 4,
                               c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
-                              c._nodes_buf.ptr, c._bounds_buf.ptr, c._flags_buf.ptr, c._alloc["scratch"].ptr,
+                              c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
                               self.counter.data_ptr(), self.pairs.data_ptr(), self.pair_capacity,
                               c._choose_sort_plan(), c._plan_word)
         call.col_translate_pairs(s, self.pairs.data_ptr(), self.counter.data_ptr(), 0, self.pair_capacity,

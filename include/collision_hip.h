@@ -117,7 +117,9 @@ int col_block_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, con
  * n keys (key_bytes 4|8) with optional values (val_bytes 0|4|8|16|32) over
  * all key bits.  Result in keys_out/vals_out; keys/vals are left untouched
  * unless copy_back != 0, which also leaves a sorted copy there as the
- * reference does (radix.py:158-169). */
+ * reference does (radix.py:158-169).
+ * Scratch sizes (here and col_collide_scratch_bytes) are monotone in n: a buffer
+ * sized for n serves every call with n' <= n of the same key/value widths. */
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes);
 int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back);
@@ -162,8 +164,13 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
 void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
+/* The col_debug_* switches are PROCESS-WIDE and unsynchronised: they select separate diagnostics instances of the
+ * kernels for every caller in the process (the production instances carry no diagnostics code).  Set them from one
+ * thread while no work is in flight; col_collide / col_collide_plan refuse to run under a forced tile class. */
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
-                                           64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU */
+                                           64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU,
+                                           2048 = persistent kernel waits for its stores too, 4096 = one-tile-per-workgroup kernel
+                                           instead of the persistent LDS-DMA one (inputs of 16 Mi elements and more) */
 int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192; 0 = automatic).  Set it BEFORE sizing
                                            scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it. */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */

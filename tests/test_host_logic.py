@@ -205,3 +205,23 @@ def test_drop_in_import_path():
     from collision_amd.collision import Collider
     assert cc.Collider is Collider and cc.NO_NODE == 0xFFFFFFFF and cc.Node.itemsize == 16
     assert hasattr(cr, "PrefixScanner") and hasattr(cr, "PrefixScanProgram")
+
+
+def test_scratch_sizes_are_monotone_in_n():
+    """A scratch buffer sized for n must serve every n' <= n (multi.py sizes the Collider once for its
+    capacity and calls col_collide with the varying number of owned spheres).  The radix tile grows with
+    n, so the histogram of a smaller input can be LARGER: the sizing functions take the maximum."""
+    from collision_amd import _lib
+    call = _lib.call
+    for kb, vb in ((4, 4), (4, 0), (8, 8), (4, 32)):
+        for thr in (1 << 20, 16 << 20):
+            sizes = [call.col_radix_scratch_bytes(n, kb, vb) for n in range(thr - 3000, thr + 3000, 256)]
+            assert sizes == sorted(sizes), (kb, vb, thr)
+    for cb in (4, 8):
+        for thr in (1 << 20, 16 << 20):
+            ns = list(range(thr - 4096, thr + 4096, 512))
+            sizes = [call.col_collide_scratch_bytes(n, n, cb) for n in ns]
+            assert sizes == sorted(sizes), (cb, thr)
+    # the two cases of the round-1 advisor note
+    assert call.col_collide_scratch_bytes(1048064, 1048064, 4) <= call.col_collide_scratch_bytes(1049088, 1049088, 4)
+    assert call.col_collide_scratch_bytes(16776704, 16776704, 4) <= call.col_collide_scratch_bytes(16777728, 16777728, 4)

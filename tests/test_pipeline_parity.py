@@ -199,6 +199,17 @@ def test_config3_clustered_matches_oracle(oracle, hip_env):
     assert count > 1000000
 
 
+def test_config3_full_size_matches_oracle(oracle, hip_env):
+    """BASELINE config 3 exactly as bench.py's config3 leg builds it: 1 M spheres in 8 Gaussian clusters,
+    sigma = 0.0152, r = 0.001, pair capacity 2^25 (about 25.4 M pairs, 51 contacts per sphere, ~50 k
+    flushes of the pair staging): every array and the whole pair set against the oracle."""
+    import bench
+    coords4, radii = bench.clustered_scene(bench.N_SPHERES, 0.0152)
+    _, _, count, pairs = check_against_oracle(oracle, hip_env, coords4[:, :3].copy(), radii, group_size=bench.GROUP_SIZE,
+                                              ngroups=bench.NGROUPS, capacity=1 << 25)
+    assert 24000000 < count < 27000000 and len(pairs) == count
+
+
 def test_single_sphere_and_tiny_scenes(oracle, hip_env):
     ctx, cq = hip_env
     for n in (1, 2):

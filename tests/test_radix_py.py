@@ -180,7 +180,7 @@ def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
         np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
 
 
-@pytest.mark.parametrize("key_dtype,val_bytes", [("uint64", 4), ("uint64", 8), ("uint32", 8), ("uint32", 16),
+@pytest.mark.parametrize("key_dtype,val_bytes", [("uint32", 4), ("uint64", 4), ("uint64", 8), ("uint32", 8), ("uint32", 16),
                                                  ("uint64", 32), ("uint32", 0), ("uint64", 0)])
 @pytest.mark.parametrize("n", [(1 << 20) + 12345, (16 << 20) + 12345])
 def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
@@ -205,3 +205,45 @@ def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
     np.testing.assert_array_equal(download(cq, ko, key_dtype, n), keys[order])
     if val_bytes:
         np.testing.assert_array_equal(download(cq, vo, np.uint8, vals.shape), vals[order])
+
+
+def _check_stable_sort(keys, out_keys, out_vals):
+    """out_vals must be THE stable argsort of keys (values were arange), out_keys the sorted keys -- checked
+    without an argsort: a permutation that gathers the sorted keys and ascends inside runs of equal keys."""
+    n = len(keys)
+    np.testing.assert_array_equal(out_keys, np.sort(keys))
+    assert (np.bincount(out_vals, minlength=n) == 1).all()                  # a permutation of arange(n)
+    np.testing.assert_array_equal(keys[out_vals], out_keys)                  # values travelled with their keys
+    same = out_keys[1:] == out_keys[:-1]
+    assert (out_vals[1:][same] > out_vals[:-1][same]).all()                  # stable
+
+
+@pytest.mark.parametrize("kind", ["morton30", "uniform32", "arange"])
+@pytest.mark.parametrize("with_values", [True, False])
+def test_config5_full_size(hip_env, kind, with_values):
+    """BASELINE config 5 at full size: 64 Mi uint32 keys (30-bit Morton-like, full 32-bit uniform, already
+    sorted -- tests/benchmarks/test_radix.py:51-55 shapes) with uint32 ids, and key-only; complete check
+    (radix.py:118-170: sorted keys, values follow their keys stably)."""
+    from collision_amd._lib import call
+    ctx, cq = hip_env
+    n = 1 << 26
+    rng = np.random.RandomState(4)
+    if kind == "morton30":
+        keys = rng.randint(0, 2 ** 30, size=n).astype(np.uint32)
+    elif kind == "uniform32":
+        keys = rng.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    else:
+        keys = np.arange(n, dtype=np.uint32)
+    kb = upload(ctx, keys)
+    ko = hip.Buffer(ctx, n * 4)
+    vb = upload(ctx, np.arange(n, dtype=np.uint32)) if with_values else None
+    vo = hip.Buffer(ctx, n * 4) if with_values else None
+    scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4 if with_values else 0))
+    call.col_radix_sort(cq.stream, kb.ptr, ko.ptr, vb.ptr if with_values else None, vo.ptr if with_values else None,
+                        n, 4, 4 if with_values else 0, scratch.ptr, 0)
+    out_keys = download(cq, ko, np.uint32, n)
+    if with_values:
+        _check_stable_sort(keys, out_keys, download(cq, vo, np.uint32, n))
+    else:
+        np.testing.assert_array_equal(out_keys, np.sort(keys))
+    np.testing.assert_array_equal(download(cq, kb, np.uint32, n), keys)     # inputs untouched (copy_back = 0)

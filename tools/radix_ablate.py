@@ -1,3 +1,5 @@
+"""Interleaved A/B timing of the 64 Mi-pair scatter pass (config 5 geometry) under the col_debug_radix modes.
+mode 0 = production (persistent LDS-DMA kernel), 4096 = the one-tile-per-workgroup kernel of round 1."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,6 +8,7 @@ from collision_amd._lib import call, cdll
 import bench
 ctx = hip.Context(); cq = hip.CommandQueue(ctx)
 n = 1 << 26
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.RandomState(4)
 keys = rng.randint(0, 2 ** 30, size=n).astype(np.uint32)
 kin, vin = hip.Buffer(ctx, hostbuf=keys), hip.Buffer(ctx, hostbuf=np.arange(n, dtype=np.uint32))
@@ -20,30 +23,47 @@ def copy():
 copy(); cq.finish()
 ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
-modes = ((0, "full"), (2, "rank + coalesced write"), (4, "blockIdx tile order (no XCD remap)"), (64, "non-temporal loads"),
-         (512, "+4.5 KB LDS per block"), (1024, "+18 KB LDS per block (1 block/CU at the 8192 tile)"))
+modes = ((0, "persistent LDS-DMA (production)"), (2048, "persistent, wait for stores too"), (2, "persistent, coalesced write"),
+         (4096, "round-1 kernel"), (4096 | 2, "round-1 kernel, coalesced write"), (4096 | 4, "round-1 kernel, blockIdx order"))
+if len(sys.argv) > 2:
+    want = set(int(x) for x in sys.argv[2].split(","))
+    modes = tuple(m for m in modes if m[0] in want)
 times = {m: [] for m, _ in modes}
 def run():
     call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)
-for rnd in range(12):                      # interleaved rounds in one process (rule 24)
+for rnd in range(rounds):                      # interleaved rounds in one process (rule 24)
     for mode, _ in modes:
         cdll().col_debug_radix(mode)
-        run(); cq.finish()
-        times[mode].append(bench.time_events(hip, cq, run, 3))
+        for _ in range(3):
+            run()
+        cq.finish()
+        times[mode].append(bench.time_events(hip, cq, run, 10))
 for mode, what in modes:
     t = sorted(times[mode])
-    print("mode %d %-26s min %.4f  median %.4f ms  -> %.0f GB/s (median)   in order: %s" % (mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6, " ".join("%.3f" % v for v in times[mode])))
-cdll().col_debug_radix(32)
-call.col_debug_radix_stamps(None, 1)
-run(); cq.finish()
-st = np.zeros(8, np.uint64)
-call.col_debug_radix_stamps(st.ctypes.data, 1)
-tot = float(st[:5].sum())
-print("k_scatter phase shares (thread 0 of every block, s_memtime):",
-      {k: round(float(v) / tot, 3) for k, v in zip(("load+transpose", "rank", "digit scan", "LDS scatter", "readback+stores"), st[:5])},
-      "cycles/block", round(tot / nb))
+    print("mode %4d %-36s min %.4f  median %.4f ms  -> %.0f GB/s = %.3f of 8 TB/s (median)   in order: %s" % (
+        mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6, n * 16 / t[len(t) // 2] / 1e6 / 8000,
+        " ".join("%.3f" % v for v in times[mode])))
+cdll().col_debug_radix(0)
+# keys only
+def run0():
+    call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, None, None, n, 4, 0, 0, hist.ptr)
+for mode in (0, 4096):
+    cdll().col_debug_radix(mode)
+    run0(); cq.finish()
+    ms = bench.time_events(hip, cq, run0, 10)
+    print("keys only, mode %d: %.4f ms -> %.0f GB/s" % (mode, ms, n * 8 / ms / 1e6))
 cdll().col_debug_radix(0)
 def h():
     call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
 h(); cq.finish()
 ms = bench.time_events(hip, cq, h, 5); print("hist %.4f ms %.0f GB/s" % (ms, n * 4 / ms / 1e6))
+def whole():
+    call.col_radix_sort(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, scratch.ptr, 0)
+scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+for mode in (0, 4096):
+    cdll().col_debug_radix(mode)
+    for _ in range(5): whole()
+    cq.finish()
+    ms = bench.time_events(hip, cq, whole, 10)
+    print("whole sort, mode %d: %.4f ms -> %.2f Gkeys/s" % (mode, ms, n / ms / 1e6))
+cdll().col_debug_radix(0)
