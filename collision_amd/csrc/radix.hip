@@ -317,14 +317,22 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     __syncthreads();
     STAMP(3)      // scatter into LDS
 
+    // Read back and stream out: consecutive lanes take consecutive tile-sorted slots, i.e. consecutive
+    // addresses inside each digit run.  (Measured and not kept: a lane taking 4 consecutive slots and
+    // storing them as one 4-byte-aligned dwordx4 -- 8 store instructions per thread instead of 32 -- is
+    // 9 % faster with the output forced coalesced and 2-10 % SLOWER on the real runs, even when every
+    // store hits L2: misaligned 16-byte stores are split in the address unit.)
 #pragma unroll
     for (int k = 0; k < IT; k++) {
         const u32 i = k * NT + tid;
         if (i < valid) {
             const K kk = s_keys[i];
             u32 g = s_goff[digit_of(kk, shift)] + i;
-            if (dbg & 2) g = (u32)tile_base + i;       // timing ablation: coalesced output
-            if (dbg & 384) {                           // timing ablations: stores at system (128) / agent (256) scope
+            if (DIAG) {
+                if (dbg & 2) g = (u32)tile_base + i;           // timing ablation: coalesced output
+                if (dbg & 32768) g &= (1u << 20) - 1;          // timing ablation: every store lands in a 4 MiB window (L2)
+            }
+            if (DIAG && (dbg & 384)) {                         // timing ablations: stores at system (128) / agent (256) scope
                 if (dbg & 128) {
                     st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&keys_out[g], kk);
                     if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&vals_out[g], s_vals[i]);
@@ -342,206 +350,6 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     STAMP(4)      // read back + global stores (issue only)
 }
 
-
-// ---- scatter, big inputs: persistent blocks, LDS-DMA double buffering ----
-// k_scatter above is one tile per workgroup: load (a third of the block's cycles is the wait for HBM),
-// rank, stage, store -- and nothing of the next tile is in flight meanwhile; two such blocks per CU
-// overlap only by chance.  Here ONE 1024-thread workgroup per CU walks its tiles, and the NEXT tile is
-// always on its way into the second LDS buffer:
-//   * loads are LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so nothing for the compiler to
-//     spill or wait on), each wave fetching its own 512-pair slice; the lane-striped order the ranking
-//     needs is then just a strided ds_read of that slice (no ds_write_b128 transposition pass);
-//   * per tile: read slice -> rank -> [B1] digit scan [B2a, B2b] -> write (key, value) PAIRS at their tile-sorted
-//     slot (one ds_write_b64) -> [B3] read back (ds_read_b64) -> [B4] wait for the DMA issued one
-//     tile ago, issue the DMA of the tile after next into the buffer just freed, store this tile;
-//   * barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would drain the stores and the DMA;
-//   * the tile's 256 scanned offsets arrive by LDS-DMA too (one dword per lane, waves 0-3), so the
-//     loop has no VGPR-destination load at all and the only vmcnt wait is the one above, for
-//     operations issued a whole tile earlier.
-// XCD-aware schedule as in k_scatter: every XCD owns a contiguous range of tiles and its workgroups
-// stride through it together, so neighbouring tiles' ~128-byte runs meet in one L2.
-constexpr int PT = 1024, PIT = 8, PNW = PT / COL_WAVE;
-constexpr int PTILE = PT * PIT;                // 8192 pairs, the BIG tile
-constexpr int PROW = COL_WAVE * PIT;           // pairs per wave
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ u32 lds_addr(const void *p) {
-    return (u32)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-// one LDS-DMA: lane l moves 16 (4) bytes from its own global address to lds_base + 16 (4) * l
-__device__ __forceinline__ void glds16(const void *gsrc, u32 lds_base) {
-    u32 keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void glds4(const void *gsrc, u32 lds_base) {
-    u32 keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
-
-template <bool HAS_V> struct ScatterPLds {
-    static constexpr int BUFW = HAS_V ? 2 * PTILE : PTILE;      // dwords per buffer: keys, then values
-    __attribute__((aligned(16))) u32 buf[2][BUFW];
-    u32 cnt[PNW][RDIG];                                         // wave-private digit counters
-    u32 raw[2][RDIG];                                           // the tile's scanned offsets, as fetched
-    u32 goff[RDIG];
-    u32 ws[RDIG / COL_WAVE];
-};
-
-// One tile of k_scatter_p from "my slice is in registers" to "sorted pairs and their global slots are in
-// registers": rank, digit scan, stage through `buf` (in place of the slices), read back.
-template <bool HAS_V, int VAR>
-__device__ __forceinline__ void scatter_p_tile(ScatterPLds<HAS_V> &L, u32 *buf, const u32 *raw, const u32 (&key)[PIT],
-                                               const u32 (&val)[HAS_V ? PIT : 1], int shift, u32 tile_base, u32 tid, u32 lane,
-                                               u32 w, u32 (&okey)[PIT], u32 (&oval)[HAS_V ? PIT : 1], u32 (&g)[PIT]) {
-    // rank inside (wave, digit): wave-private counters, program order keeps them consistent
-    u32 pos[PIT];
-#pragma unroll
-    for (int k = 0; k < PIT; k++) {
-        const u32 d = digit_of(key[k], shift);
-        const u64 peers = match8(d);
-        const u32 below = mbcnt(peers);
-        const u32 prev = L.cnt[w][d];
-        if (below == 0) L.cnt[w][d] = prev + (u32)__popcll(peers);
-        pos[k] = prev + below;
-    }
-    lds_barrier();                                                            // B1: counters complete, slices read
-
-    // digit `tid` (waves 0-3): exclusive over waves, then over digits
-    u32 c[PNW], tot = 0, incl = 0;
-    if (tid < RDIG) {
-#pragma unroll
-        for (int i = 0; i < PNW; i++) { c[i] = L.cnt[i][tid]; tot += c[i]; }
-        incl = wave_incl_scan(tot);
-        if (lane == COL_WAVE - 1) L.ws[w] = incl;
-    }
-    lds_barrier();                                                            // B2a
-    if (tid < RDIG) {
-        u32 run = incl - tot;
-#pragma unroll
-        for (int i = 0; i < RDIG / COL_WAVE; i++) run += ((u32)i < w ? L.ws[i] : 0u);
-        L.goff[tid] = raw[tid] - run;       // global position of tile-sorted slot i with digit d is goff[d] + i
-#pragma unroll
-        for (int i = 0; i < PNW; i++) { L.cnt[i][tid] = run; run += c[i]; }
-    }
-    lds_barrier();                                                            // B2b
-
-    // (key, value) PAIRS to their tile-sorted slot: one ds_write_b64 per item
-#pragma unroll
-    for (int k = 0; k < PIT; k++) {
-        const u32 p = pos[k] + L.cnt[w][digit_of(key[k], shift)];
-        if (HAS_V) reinterpret_cast<uint2 *>(buf)[p] = make_uint2(key[k], val[k]);
-        else buf[p] = key[k];
-    }
-    lds_barrier();                                                            // B3
-
-#pragma unroll
-    for (int k = 0; k < PIT; k++) {
-        const u32 i = k * PT + tid;
-        if (HAS_V) {
-            const uint2 kv = reinterpret_cast<const uint2 *>(buf)[i];
-            okey[k] = kv.x; oval[k] = kv.y;
-        } else okey[k] = buf[i];
-        g[k] = L.goff[digit_of(okey[k], shift)] + i;
-        if (VAR & 1) g[k] = tile_base + i;                                   // timing ablation: coalesced output
-    }
-    for (u32 i = lane; i < RDIG; i += COL_WAVE) L.cnt[w][i] = 0;            // for the next tile (wave-private)
-    lds_barrier();                                                            // B4: `buf` is free again
-}
-
-// VAR (timing ablations, col_debug_radix): bit 0 = coalesced output, bit 1 = wait for everything (stores
-// too) before the next DMA instead of the counted wait.
-template <bool HAS_V, int VAR>
-__global__ __launch_bounds__(PT) void k_scatter_p(const u32 *__restrict__ keys_in, u32 *__restrict__ keys_out,
-                                                  const u32 *__restrict__ vals_in, u32 *__restrict__ vals_out,
-                                                  uint64_t n, u32 nblocks, int shift, const u32 *__restrict__ offsets) {
-    __shared__ ScatterPLds<HAS_V> L;
-    const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1);
-    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid / COL_WAVE));
-
-    // this workgroup's tiles: first, first + step, ... < end
-    u32 first, step, end;
-    if (gridDim.x >= 8) {
-        const u32 q = nblocks / 8, r = nblocks % 8, xcd = blockIdx.x % 8;
-        const u32 lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        first = lo + blockIdx.x / 8;
-        step = (gridDim.x + 7 - xcd) / 8;
-        end = lo + q + (xcd < r ? 1u : 0u);
-    } else {
-        first = blockIdx.x; step = gridDim.x; end = nblocks;
-    }
-    // The pipelined loop takes FULL tiles only (it has no VGPR-destination load, so hipcc places no vmcnt
-    // wait in it); the ragged last tile of the input, if this workgroup owns it, follows the loop.
-    const u32 n_full = (u32)(n / PTILE);
-    const u32 end_full = end < n_full ? end : n_full;
-
-    // DMA of a full `tile` into buffer `sel`: this wave's slice of the keys (and values), plus (waves 0-3)
-    // 64 of the tile's 256 scanned offsets
-    auto issue = [&](u32 tile, u32 sel) {
-        if (tile >= end_full) return;
-        const uint64_t base = (uint64_t)tile * PTILE + w * PROW;
-#pragma unroll
-        for (int j = 0; j < PROW / 256; j++) {
-            glds16(keys_in + base + j * 256 + lane * 4, lds_addr(&L.buf[sel][w * PROW + j * 256]));
-            if (HAS_V) glds16(vals_in + base + j * 256 + lane * 4, lds_addr(&L.buf[sel][PTILE + w * PROW + j * 256]));
-        }
-        if (w < RDIG / COL_WAVE) glds4(offsets + (uint64_t)tid * nblocks + tile, lds_addr(&L.raw[sel][w * COL_WAVE]));
-    };
-
-    for (u32 i = lane; i < RDIG; i += COL_WAVE) L.cnt[w][i] = 0;
-    issue(first, 0);
-    issue(first + step, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    u32 sel = 0;
-    for (u32 tile = first; tile < end_full; tile += step, sel ^= 1) {
-        u32 *buf = L.buf[sel];
-        // my slice, lane-striped: (wave, item, lane) order == memory order, stability is positional
-        u32 key[PIT], val[HAS_V ? PIT : 1], okey[PIT], oval[HAS_V ? PIT : 1], g[PIT];
-#pragma unroll
-        for (int k = 0; k < PIT; k++) key[k] = buf[w * PROW + k * COL_WAVE + lane];
-        if (HAS_V) {
-#pragma unroll
-            for (int k = 0; k < PIT; k++) val[k] = buf[PTILE + w * PROW + k * COL_WAVE + lane];
-        }
-        scatter_p_tile<HAS_V, VAR>(L, buf, L.raw[sel], key, val, shift, tile * (u32)PTILE, tid, lane, w, okey, oval, g);
-        // The DMA of the next tile and the stores of the previous one were issued a whole tile ago, in that
-        // order: waiting for all but the youngest 2 * PIT (the stores) operations waits for the DMA only.
-        if (VAR & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HAS_V ? 2 * PIT : PIT) : "memory");
-        issue(tile + 2 * step, sel);
-#pragma unroll
-        for (int k = 0; k < PIT; k++) {
-            keys_out[g[k]] = okey[k];
-            if (HAS_V) vals_out[g[k]] = oval[k];
-        }
-    }
-
-    if (end == nblocks && n_full < nblocks && (nblocks - 1 - first) % step == 0 && nblocks - 1 >= first) {
-        // the ragged last tile: loaded synchronously; pads sort last (positional stability) and are never stored
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u32 tile = nblocks - 1;
-        const uint64_t tile_base = (uint64_t)tile * PTILE;
-        const u32 valid = (u32)(n - tile_base);
-        u32 key[PIT], val[HAS_V ? PIT : 1], okey[PIT], oval[HAS_V ? PIT : 1], g[PIT];
-#pragma unroll
-        for (int k = 0; k < PIT; k++) {
-            const u32 li = w * PROW + k * COL_WAVE + lane;
-            key[k] = li < valid ? keys_in[tile_base + li] : 0xFFFFFFFFu;
-            if (HAS_V) val[k] = li < valid ? vals_in[tile_base + li] : 0u;
-        }
-        if (tid < RDIG) L.raw[0][tid] = offsets[(uint64_t)tid * nblocks + tile];     // read back by the same thread
-        scatter_p_tile<HAS_V, VAR>(L, L.buf[0], L.raw[0], key, val, shift, (u32)tile_base, tid, lane, w, okey, oval, g);
-#pragma unroll
-        for (int k = 0; k < PIT; k++) {
-            if ((u32)k * PT + tid < valid) {
-                keys_out[g[k]] = okey[k];
-                if (HAS_V) vals_out[g[k]] = oval[k];
-            }
-        }
-    }
-}
 
 // ---- MSD finish: one block sorts one top-digit bucket on its remaining low bits ----
 // col_radix_sort_msd (small inputs, launch-bound): ONE global pass on the top 8 significant bits
@@ -877,23 +685,6 @@ int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const voi
     }
 }
 
-// the persistent LDS-DMA kernel: u32 keys, no or 4-byte values, the BIG tile
-constexpr int P_MAX_BLOCKS = 256;          // one 1024-thread workgroup (147 KB of LDS) per CU
-template <bool HAS_V>
-int launch_scatter_p(hipStream_t s, const u32 *ki, u32 *ko, const u32 *vi, u32 *vo, uint64_t n, int shift, const u32 *offsets) {
-    const u32 nb = (u32)col_ceil_div(n, PTILE);
-    dim3 grid(nb < (u32)P_MAX_BLOCKS ? nb : (u32)P_MAX_BLOCKS), block(PT);
-    const int var = (g_radix_dbg & 2 ? 1 : 0) | (g_radix_dbg & 2048 ? 2 : 0);
-    switch (var) {
-    case 0: k_scatter_p<HAS_V, 0><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
-    case 1: k_scatter_p<HAS_V, 1><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
-    case 2: k_scatter_p<HAS_V, 2><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
-    default: k_scatter_p<HAS_V, 3><<<grid, block, 0, s>>>(ki, ko, vi, vo, n, nb, shift, offsets); break;
-    }
-    COL_LAUNCH_OK();
-    return COL_OK;
-}
-
 template <typename K>
 int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int vb, int shift, const u32 *offsets) {
@@ -902,14 +693,8 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
         return launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
     if (tile == (u32)(NT_MID * IT_BIG))
         return launch_scatter_it<K, IT_BIG, NT_MID>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
-    if constexpr (sizeof(K) == 4) {
-        const bool has_v = vals && vals_out && vb;
-        if ((!has_v || vb == 4) && !(g_radix_dbg & 4096)) {      // mode 4096: the one-tile-per-workgroup kernel instead
-            if (has_v) return launch_scatter_p<true>(s, (const u32 *)keys, (u32 *)keys_out, (const u32 *)vals, (u32 *)vals_out, n, shift, offsets);
-            return launch_scatter_p<false>(s, (const u32 *)keys, (u32 *)keys_out, nullptr, nullptr, n, shift, offsets);
-        }
+    if constexpr (sizeof(K) == 4)
         return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
-    }
     return COL_EINVAL;
 }
 

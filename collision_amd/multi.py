@@ -396,6 +396,7 @@ class DistributedCollider:
         else:
             own_rows, own_gids, m = rows, gids, n
         self.stats["owned"] = m
+        self.own_rows, self.own_gids, self.n_owned = own_rows, own_gids, m      # (tests read these back)
 
         # 3. the single-GPU path on the owned spheres
         e.collide(own_rows, own_gids, m)

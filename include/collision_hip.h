@@ -169,8 +169,7 @@ void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_ch
  * thread while no work is in flight; col_collide / col_collide_plan refuse to run under a forced tile class. */
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
                                            64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU,
-                                           2048 = persistent kernel waits for its stores too, 4096 = one-tile-per-workgroup kernel
-                                           instead of the persistent LDS-DMA one (inputs of 16 Mi elements and more) */
+                                           32768 = every store lands in a 4 MiB window */
 int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192; 0 = automatic).  Set it BEFORE sizing
                                            scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it. */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */

@@ -164,6 +164,44 @@ def scene(n, world, kind, seed=4):
     return coords, radii
 
 
+def per_rank_parity(dc):
+    """this rank's sorted codes / ids, node records and node boxes must equal the oracle run
+    on the spheres this rank owns (the local pipeline normalises with the bounds of that subset, exactly
+    as the single-GPU path does).  Returns "ok" or a description of the first mismatch."""
+    import oracle
+    from collision_amd.collision import Node
+    from collision_amd.misc import roundUp
+    e, m = dc.engine, dc.n_owned
+    if m < 2:
+        return "ok"
+    rows = dc.own_rows[:m].cpu().numpy().copy()
+    radii = rows[:, 3].copy()
+    c = e.collider
+    padded = roundUp(m, 2 * e.group_size)
+    ref = oracle.collide(rows, radii, padded=padded, capacity=0, want=True)
+    cq = e.cq
+    codes = hip_read(cq, c._codes_bufs[1], np.uint32, padded)
+    ids = hip_read(cq, c._ids_bufs[1], np.uint32, padded)
+    nodes = hip_read(cq, c._nodes_buf, Node, 2 * m - 1)
+    bounds = hip_read(cq, c._bounds_buf, np.float32, (2 * m - 1, 2, 4))
+    leaf = m - 1
+    checks = (("codes", codes, ref["codes"]), ("ids", ids, ref["ids"]),
+              ("right_edge", nodes["right_edge"], ref["nodes"]["right_edge"]),
+              ("parent", nodes["parent"][1:], ref["nodes"]["parent"][1:]),
+              ("children", nodes["data"][:leaf], ref["nodes"]["data"][:leaf]),
+              ("leaf ids", nodes["data"][leaf:, 0], ref["nodes"]["data"][leaf:, 0]),
+              ("boxes", bounds[:, :, :3], ref["bounds"][:, :, :3]))
+    for name, got, want in checks:
+        if not np.array_equal(got, want):
+            return "rank %d: %s differ from the oracle on its %d owned spheres" % (dc.rank, name, m)
+    return "ok"
+
+
+def hip_read(cq, buf, dtype, shape):
+    from collision_amd import hip
+    return hip.read_buffer(cq, buf, dtype, shape)
+
+
 def main():
     mode, partition, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
@@ -190,8 +228,11 @@ def main():
     dc.synchronize()
     pairs = dc.local_pairs()
     total = dc.global_pair_count()
+    stats = dict(dc.stats)
+    if mode == "gpu":
+        stats["rank_parity"] = per_rank_parity(dc)
     gathered = [None] * world
-    dist.gather_object((pairs, dict(dc.stats)), gathered if rank == 0 else None, dst=0)
+    dist.gather_object((pairs, stats), gathered if rank == 0 else None, dst=0)
     if rank == 0:
         import oracle
         cnt, ref = oracle.brute_force(coords, radii)
@@ -199,7 +240,8 @@ def main():
         got = []
         for p, _ in gathered:
             got += [tuple(sorted(t)) for t in p.tolist()]
-        result = {"ok": len(got) == len(set(got)) == cnt and set(got) == expect and total == cnt,
+        parity_ok = all(s.get("rank_parity", "ok") == "ok" for _, s in gathered)
+        result = {"ok": len(got) == len(set(got)) == cnt and set(got) == expect and total == cnt and parity_ok,
                   "expected": cnt, "found": len(got), "unique": len(set(got)), "global_count": total,
                   "stats": [s for _, s in gathered], "world": world, "partition": partition, "mode": mode}
         Path(out).write_text(json.dumps(result))

@@ -55,12 +55,28 @@ def test_gloo_cpu_world(tmp_path, world, partition, kind):
     assert res["expected"] > 100
 
 
+@pytest.mark.parametrize("partition,kind", [("hash", "uniform"), ("morton", "uniform"), ("morton", "clustered")])
+def test_gloo_cpu_world8(tmp_path, partition, kind):
+    """BASELINE config 4's rank count: world = 8 (every rank has 3-4 halo peers under the ownership rule;
+    with the hash partition every rank's region is the whole scene).  Union of all ranks' pairs == brute
+    force, each pair once."""
+    res = _run(8, "cpu", partition, 4000, tmp_path, kind, port=29651 + (partition == "hash") + 2 * (kind == "clustered"))
+    assert res["ok"], res
+    assert res["world"] == 8 and res["expected"] > 500
+    assert all(s["owned"] > 0 for s in res["stats"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,partition,kind,n", [(2, "morton", "uniform", 60000), (2, "hash", "uniform", 20000),
-                                                    (4, "morton", "clustered", 40000)])
+                                                    (4, "morton", "clustered", 40000), (6, "morton", "uniform", 120000),
+                                                    (6, "hash", "clustered", 30000)])
 def test_gloo_gpu_rehearsal(tmp_path, world, partition, kind, n):
-    res = _run(world, "gpu", partition, n, tmp_path, kind, port=29631 + world)
+    """The real HIP engine on every rank, ranks sharing the one GPU of the test box (at most 6 processes
+    may use it).  Besides the global pair set, every rank's sorted codes / ids, node records and boxes
+    are compared with the oracle on the spheres that rank owns (dist_worker.per_rank_parity)."""
+    res = _run(world, "gpu", partition, n, tmp_path, kind, port=29631 + world + 10 * (partition == "hash"))
     assert res["ok"], res
+    assert all(s["rank_parity"] == "ok" for s in res["stats"])
     if partition == "morton" and kind == "uniform":      # a spatial partition keeps the halo thin
         assert max(s["ghosts"] for s in res["stats"]) < 0.6 * n / world
 

@@ -1,5 +1,4 @@
-"""Interleaved A/B timing of the 64 Mi-pair scatter pass (config 5 geometry) under the col_debug_radix modes.
-mode 0 = production (persistent LDS-DMA kernel), 4096 = the one-tile-per-workgroup kernel of round 1."""
+"""Interleaved A/B timing of the 64 Mi-pair scatter pass (config 5 geometry) under the col_debug_radix modes."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,8 +22,8 @@ def copy():
 copy(); cq.finish()
 ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
-modes = ((0, "persistent LDS-DMA (production)"), (2048, "persistent, wait for stores too"), (2, "persistent, coalesced write"),
-         (4096, "round-1 kernel"), (4096 | 2, "round-1 kernel, coalesced write"), (4096 | 4, "round-1 kernel, blockIdx order"))
+modes = ((0, "production"), (1 << 30, "production (diag instance)"), (2, "coalesced write"), (4, "blockIdx tile order"),
+         (64, "non-temporal loads"), (32768, "4 MiB output window (stores hit L2)"))
 if len(sys.argv) > 2:
     want = set(int(x) for x in sys.argv[2].split(","))
     modes = tuple(m for m in modes if m[0] in want)
@@ -47,7 +46,7 @@ cdll().col_debug_radix(0)
 # keys only
 def run0():
     call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, None, None, n, 4, 0, 0, hist.ptr)
-for mode in (0, 4096):
+for mode in (0,):
     cdll().col_debug_radix(mode)
     run0(); cq.finish()
     ms = bench.time_events(hip, cq, run0, 10)
@@ -60,7 +59,7 @@ ms = bench.time_events(hip, cq, h, 5); print("hist %.4f ms %.0f GB/s" % (ms, n *
 def whole():
     call.col_radix_sort(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, scratch.ptr, 0)
 scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
-for mode in (0, 4096):
+for mode in (0,):
     cdll().col_debug_radix(mode)
     for _ in range(5): whole()
     cq.finish()
