@@ -6,9 +6,11 @@ the HBM roofline claim.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1: one process.  N > 1: launched by torch.distributed.run, one rank per GPU (RCCL); every
-rank holds 1 M spheres of an N x 1 M scene (weak scaling), see collision_amd/multi.py.
-Rank 0 prints ONE JSON line.  A "step" is one get_collisions over device-resident inputs.
+N = 1: one process, BASELINE config 2 (1 M spheres).  N > 1: launched by torch.distributed.run, one rank
+per GPU (RCCL); BASELINE config 4's workload -- every rank ARRIVES with the hash(id) mod N share of an
+(N x 2 M)-sphere uniform scene (16 M spheres at N = 8), see collision_amd/multi.py; the same run at
+1 M spheres per rank is reported beside it (`weak_1M_per_rank`).  Rank 0 prints ONE JSON line.  A "step"
+is one get_collisions (N = 1) / one DistributedCollider.step (N > 1) over device-resident inputs.
 """
 import argparse
 import json
@@ -30,7 +32,8 @@ NGROUPS = 64
 PAIR_CAPACITY = 1 << 17
 SORT_KEYS = 1 << 26         # BASELINE config 5
 SORT_WARMUP = 20            # whole sorts before the timed ones
-SCATTER_WARMUP, SCATTER_TIMED = 100, 50     # k_scatter launches: untimed, then the timed region
+SCATTER_WARMUP, SCATTER_TIMED = 100, 200    # k_scatter launches: untimed, then the timed region (one event per launch)
+N_PER_RANK_MULTI = 2000000  # BASELINE config 4: 16 M spheres over 8 GPUs
 
 
 def uniform_scene(n, seed=4):
@@ -50,6 +53,19 @@ def time_events(hip, cq, fn, reps):
     call.col_event_record(stop.handle, cq.stream)
     stop.wait()
     return start.elapsed_ms(stop) / reps
+
+
+def time_events_each(hip, cq, fn, reps):
+    """Per-launch device times (ms) of `reps` back-to-back fn() calls: one HIP event between consecutive
+    launches on the launch stream.  Returns the sorted list."""
+    from collision_amd._lib import call
+    events = [hip.Event() for _ in range(reps + 1)]
+    call.col_event_record(events[0].handle, cq.stream)
+    for i in range(reps):
+        fn()
+        call.col_event_record(events[i + 1].handle, cq.stream)
+    events[-1].wait()
+    return sorted(events[i].elapsed_ms(events[i + 1]) for i in range(reps))
 
 
 def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
@@ -89,7 +105,10 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         for _ in range(SCATTER_WARMUP):
             scatter()
         cq.finish()
-        res[name] = time_events(hip, cq, scatter, SCATTER_TIMED)       # steady state: the timed region
+        each = time_events_each(hip, cq, scatter, SCATTER_TIMED)       # steady state: the timed region
+        res[name] = each[len(each) // 2]                               # median launch
+        res[name + "_mean"] = sum(each) / len(each)
+        res[name + "_p10_p90"] = (each[len(each) // 10], each[(9 * len(each)) // 10])
 
     def histo():
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
@@ -102,7 +121,7 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         "n_keys": n, "sort_ms": sort_ms, "gkeys_per_s": n / sort_ms / 1e6, "tile": tile,
         "scatter_ms": scatter_ms, "scatter_ms_top_digit": res["pass3"], "hist_ms": hist_ms,
         "scatter_gbs": algo_bytes / scatter_ms / 1e6,
-        "scatter_ms_cold": res["pass0_cold"],
+        "scatter_ms_cold": res["pass0_cold"], "scatter_ms_mean": res["pass0_mean"], "scatter_ms_p10_p90": res["pass0_p10_p90"],
         "algo_bytes_per_launch": algo_bytes,
     }
 
@@ -138,6 +157,25 @@ def config3_leg(hip, ctx, cq, reps=5):
             "contacts_per_sphere": round(2.0 * pairs / N_SPHERES, 1), "m_pairs_per_s": round(pairs / ms / 1e3, 1)}
 
 
+def single_gpu_leg(hip, ctx, cq, n, reps=20):
+    """The single-GPU path at another size (config 4's 2 M spheres per rank), same generator and contact density."""
+    from collision_amd.collision import Collider
+    coords, radii = uniform_scene(n)
+    radii[:] = RADIUS * (1e6 / n) ** (1.0 / 3.0)
+    cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
+    nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, PAIR_CAPACITY * 8)
+    col = Collider(ctx, n, NGROUPS, GROUP_SIZE)
+
+    def run():
+        col.get_collisions(cq, cb, rb, nb, pb, PAIR_CAPACITY)
+    for _ in range(5):
+        run()
+    cq.finish()
+    ms = time_events(hip, cq, run, reps)
+    return {"spheres": n, "ms_per_step": round(ms, 4), "m_spheres_per_s": round(n / ms / 1e3, 1),
+            "pairs": int(hip.read_buffer(cq, nb, np.uint32, 1)[0])}
+
+
 def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
     """Config 5 key distributions (tests/benchmarks/test_radix.py:51-55 shapes): Gkeys/s each."""
     from collision_amd._lib import call
@@ -162,23 +200,115 @@ def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per k_scatter launch from the committed rocprofv3 PMC passes (separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of tools/radix_only.py, summarised by tools/summarize_prof.py).
-    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a coalesced
-    streaming read -- checked here on k_hist, which reads exactly n*4 bytes and reports n*2 -- so
-    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  None if the summary is not present."""
-    f = ROOT / "profiles" / "r01_radix64M_pmc.json"
-    if not f.exists():
-        return None
-    summary = json.loads(f.read_text())
-    # the 64 Mi-pair instance: k_scatter<u32 key, 4-byte value, 16 items/thread, 512 threads>
-    names = [k for k in summary if k.startswith("k_scatter<unsigned int, 4")]
-    names.sort(key=lambda k: ("16, 512" not in k, k))
-    d = summary[names[0]] if names else None
-    if not d or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
-        return None
-    return (2.0 * d["FETCH_SIZE"]["median"] + d["WRITE_SIZE"]["median"]) * 1024.0
+def pmc_traffic(timeout_s=150):
+    """HBM bytes per k_scatter launch, measured in THIS run: two child processes run the same radix
+    microbench (tools/radix_only.py) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE in separate passes
+    (MI355X_MICROARCH.md, rocprofv3 PMC slots: they do not fit one pass), after the timed region.
+    gfx950 correction (same guide, HBM): FETCH_SIZE reports half the bytes of a coalesced 16-byte-per-lane
+    streaming read -- calibrated here on k_hist of the same pass, which reads exactly n * 4 bytes -- so
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes or None, detail dict)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    detail = {}
+    med = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="col_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            proc = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out,
+                                   "-o", "pmc", "--", sys.executable, str(ROOT / "tools" / "radix_only.py"), "1"],
+                                  cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if proc.returncode != 0:
+                detail[counter] = "rocprofv3 rc %d: %s" % (proc.returncode, proc.stderr[-300:])
+                return None, detail
+            per = {"k_scatter": [], "k_hist": []}
+            for f in Path(out).rglob("*counter_collection.csv"):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for kern in per:
+                        if kern + "<unsigned int" in row["Kernel_Name"]:
+                            per[kern].append(float(row["Counter_Value"]))
+            for kern, v in per.items():
+                if v:
+                    v.sort()
+                    med[(kern, counter)] = v[len(v) // 2]
+                    detail["%s_%s_KB_median" % (kern, counter)] = v[len(v) // 2]
+                    detail["%s_launches" % kern] = len(v)
+        except Exception as exc:                       # a profiler problem must not lose the bench line
+            detail[counter] = repr(exc)
+            return None, detail
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    if ("k_scatter", "FETCH_SIZE") not in med or ("k_scatter", "WRITE_SIZE") not in med:
+        return None, detail
+    if ("k_hist", "FETCH_SIZE") in med:               # calibration: k_hist reads n * 4 bytes
+        detail["fetch_correction_measured_on_k_hist"] = round(SORT_KEYS * 4 / 1024.0 / med[("k_hist", "FETCH_SIZE")], 3)
+    return (2.0 * med[("k_scatter", "FETCH_SIZE")] + med[("k_scatter", "WRITE_SIZE")]) * 1024.0, detail
+
+
+def reference_benchmark_shapes(hip, ctx, cq):
+    """The reference's remaining pytest-benchmark workloads (tests/benchmarks/test_scan.py:29-53,
+    test_bounds.py:18-41, test_offset.py:24-39, test_radix.py:51-139, test_collide.py:24-54), timed the
+    way it does (device-resident inputs, enqueue -> done), ms per call."""
+    from collision_amd._lib import call
+    from collision_amd.bounds import Bounds
+    from collision_amd.collision import Collider
+    from collision_amd.offset import OffsetFinder
+    from collision_amd.radix import RadixSorter
+    from collision_amd.scan import PrefixScanner
+    rng = np.random.RandomState(4)
+    out = {}
+
+    def timed(fn, reps=50):
+        for _ in range(10):                                    # warmup_rounds=10 as the reference
+            fn()
+        cq.finish()
+        return round(time_events(hip, cq, fn, reps), 5)
+
+    for size in (307200, 1536000, 3072000):                    # test_scan.py
+        vals = rng.randint(0, 128, size=size).astype(np.uint32)
+        buf = hip.Buffer(ctx, hostbuf=vals)
+        scanner = PrefixScanner(ctx, size, 128)
+        out["scan_u32_%d" % size] = timed(lambda: scanner.prefix_sum(cq, buf))
+    for size in (1536000, 3072000):                            # test_bounds.py
+        rows = rng.uniform(0, 1, size=(size, 4)).astype(np.float32)
+        buf, outb = hip.Buffer(ctx, hostbuf=rows), hip.Buffer(ctx, 64)
+        bounds = Bounds(ctx, 64, 128, coord_dtype=np.dtype((np.float32, 4)))
+        out["bounds_f32x4_%d" % size] = timed(lambda: bounds.reduce(cq, size, buf, outb))
+    for maxval in (2000, 2000000):                             # test_offset.py
+        size = 1 << 21
+        vals = np.sort(rng.randint(0, maxval, size=size).astype(np.uint32))
+        vb, ob = hip.Buffer(ctx, hostbuf=vals), hip.Buffer(ctx, (maxval + 1) * 4)
+        finder = OffsetFinder(ctx)
+        out["offsets_2e21_max%d" % maxval] = timed(lambda: finder.find_offsets(cq, vb, size, ob, maxval + 1))
+    size = 307200                                              # test_radix.py
+    for name, keys in (("randint1000", rng.randint(0, 1000, size=size)), ("randint307200", rng.randint(0, size, size=size)),
+                       ("arange", np.arange(size))):
+        for kd in ("uint32", "uint64"):
+            kb = hip.Buffer(ctx, hostbuf=keys.astype(kd))
+            ko = hip.Buffer(ctx, size * np.dtype(kd).itemsize)
+            sorter = RadixSorter(ctx, size, 128, key_dtype=np.dtype(kd))
+            out["radix_keys_%s_%s" % (kd, name)] = timed(lambda: sorter.sort(cq, kb, ko))
+    keys = rng.randint(0, size, size=size).astype(np.uint32)
+    for vname, vdt in (("u32", np.dtype("uint32")), ("f64", np.dtype("float64")), ("f32x3", np.dtype(("float32", 3))),
+                       ("f32x4", np.dtype(("float32", 4)))):
+        sorter = RadixSorter(ctx, size, 128, key_dtype=np.dtype("uint32"), value_dtype=vdt)
+        kb, ko = hip.Buffer(ctx, hostbuf=keys), hip.Buffer(ctx, size * 4)
+        vb, vo = hip.Buffer(ctx, size * sorter.value_bytes), hip.Buffer(ctx, size * sorter.value_bytes)
+        out["radix_pairs_u32_%s" % vname] = timed(lambda: sorter.sort(cq, kb, ko, vb, vo))
+    for size in (307200, 307201):                              # test_collide.py: count-only mode
+        coords = np.zeros((size, 4), np.float32)
+        coords[:, :3] = rng.uniform(-1, 1, size=(size, 3))
+        radii = rng.uniform(0.006, 0.06, size=size).astype(np.float32)
+        cb, rb, nb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii), hip.Buffer(ctx, 4)
+        col = Collider(ctx, size, 8, 128)
+        out["collide_count_only_%d" % size] = timed(lambda: col.get_collisions(cq, cb, rb, nb, None, 0), reps=10)
+    return out
 
 
 def cpu_baseline(coords, radii, budget_s=12.0, max_runs=20):
@@ -229,6 +359,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-radix", action="store_true", help="skip the 64Mi-key radix microbench")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic)")
     ap.add_argument("--partition", default="morton", choices=["morton", "hash"],
                     help="multi-GPU: repartition spatially (default) or keep the id-hash partition")
     args = ap.parse_args()
@@ -278,11 +409,17 @@ def main():
         parallelism = "single"
     else:
         from collision_amd.multi import DistributedCollider, make_rank_scene
-        engine = DistributedCollider(ctx, dist, N_SPHERES, group_size=GROUP_SIZE, pair_capacity=PAIR_CAPACITY * 4,
-                                     partition=args.partition)
+
+        def make_engine(n_per_rank):
+            eng = DistributedCollider(ctx, dist, n_per_rank, group_size=GROUP_SIZE, pair_capacity=PAIR_CAPACITY * 8,
+                                      partition=args.partition)
+            # r shrinks with the density so that contacts per sphere stay those of config 2
+            c, r, g = make_rank_scene(n_per_rank, rank, world, RADIUS * (1e6 / n_per_rank) ** (1.0 / 3.0))
+            eng.set_local_spheres(c, r, g)
+            return eng
+
+        engine = make_engine(N_PER_RANK_MULTI)
         cq = engine.cq
-        coords, radii, gids = make_rank_scene(N_SPHERES, rank, world, RADIUS)
-        engine.set_local_spheres(coords, radii, gids)
 
         def step():
             engine.step()
@@ -290,30 +427,35 @@ def main():
         def sync():
             engine.synchronize()
 
-        total_spheres = N_SPHERES * world
-        parallelism = "%s-partition x%d, RCCL AABB all-gather + halo exchange" % (args.partition, world)
+        total_spheres = N_PER_RANK_MULTI * world
+        parallelism = "hash(id) mod %d arrival, %s repartition, RCCL AABB all-gathers + halo exchange" % (world, args.partition)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(step_fn, sync_fn):
+        """W untimed steps, then exactly K steps between barrier + sync on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            step_fn()
+        sync_fn()
+        barrier()
+        sync_fn()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        sync_fn()
+        barrier()
+        sync_fn()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed_region(step, sync)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_spheres / (elapsed / args.steps) / 1e6
 
@@ -321,6 +463,15 @@ def main():
         pair_count = int(hip.read_buffer(cq, n_buf, np.uint32, 1)[0])
     else:
         pair_count = engine.global_pair_count()
+        extra["per_rank"] = {"owned_spheres_rank0": engine.stats.get("owned"), "ghost_queries_rank0": engine.stats.get("ghosts")}
+        # the same protocol at 1 M spheres per rank (round 1's line), reported beside the config-4 workload
+        del engine
+        engine1 = make_engine(N_SPHERES)
+        dt1 = timed_region(engine1.step, engine1.synchronize)
+        extra["weak_1M_per_rank"] = {"workload": "%d x 1M spheres, same protocol" % world, "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                                     "m_spheres_per_s": round(N_SPHERES * world / (dt1 / args.steps) / 1e6, 2),
+                                     "pairs_found": engine1.global_pair_count()}
+        cq = engine1.cq
     extra["pairs_found"] = pair_count
 
     result = None
@@ -348,11 +499,16 @@ def main():
                         "achieved": round(rb["scatter_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(rb["scatter_gbs"] / HBM_PEAK_GBS, 4),
                         "algo_bytes_per_launch": rb["algo_bytes_per_launch"],
-                        "launch_ms": round(rb["scatter_ms"], 4),
+                        "launch_ms": round(rb["scatter_ms"], 4), "launch_ms_is": "median of the timed launches (one HIP event per launch)",
+                        "launch_ms_mean": round(rb["scatter_ms_mean"], 4),
+                        "launch_ms_p10_p90": [round(v, 4) for v in rb["scatter_ms_p10_p90"]],
                         "launches_timed": SCATTER_TIMED, "warmup_launches": SCATTER_WARMUP,
                         "launch_ms_first_20_after_idle": round(rb["scatter_ms_cold"], 4),
-                        "traffic": pmc_traffic(),
-                        "traffic_source": "profiles/r01_radix64M_pmc.json (rocprofv3 --pmc, offline pass)"}
+                        "traffic": None}
+            if world == 1 and not args.no_pmc:
+                roofline["traffic"], roofline["traffic_detail"] = pmc_traffic()
+                roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of tools/radix_only.py in this "
+                                              "run; bytes = (2 * FETCH + WRITE) * 1024")
         if world == 1:
             # per-stage device times of the 1M path (HIP events on the launch stream)
             from collision_amd.stages import stage_times
@@ -368,6 +524,8 @@ def main():
             if not args.no_radix:
                 extra["config3_clustered"] = config3_leg(hip, ctx, cq)
                 extra["radix_sort"]["gkeys_per_s_other_distributions"] = config5_variants(hip, ctx, cq)
+                extra["config4_per_rank_size_on_one_gpu"] = single_gpu_leg(hip, ctx, cq, N_PER_RANK_MULTI)
+                extra["reference_benchmark_shapes_ms"] = reference_benchmark_shapes(hip, ctx, cq)
         cpu = None
         if not args.no_cpu and world == 1:
             cpu = cpu_baseline(coords, radii)
@@ -378,8 +536,11 @@ def main():
             "value": round(value, 2), "unit": "M spheres/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 coords / u32 keys+ids", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d uniform-random spheres per GPU, r=%g, f32, "
-                                   "RandomState(4), pair capacity %d" % (N_SPHERES, RADIUS, PAIR_CAPACITY),
+            "config": {"workload": ("BASELINE config 2: %d uniform-random spheres, r=%g, f32, RandomState(4), pair capacity %d"
+                                    % (N_SPHERES, RADIUS, PAIR_CAPACITY)) if world == 1 else
+                                   ("BASELINE config 4: %d uniform-random spheres (RandomState(4)) arriving hash(id) mod %d "
+                                    "partitioned, %d per GPU, r=%.3g (contacts per sphere of config 2), f32"
+                                    % (total_spheres, world, N_PER_RANK_MULTI, RADIUS * (1e6 / total_spheres) ** (1.0 / 3.0))),
                        "spheres_total": total_spheres, "group_size": GROUP_SIZE, "parallelism": parallelism},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -60,7 +60,7 @@ class Collider:
                 raise ValueError("Collider and program coord_dtype must match")
         self.program = program
         self._alloc = {}              # device scratch, (re)allocated at first use after a size change
-        # Sort plan for inputs below 1 Mi spheres (include/collision_hip.h, col_collide_plan): the MSD sort
+        # Sort plan for inputs of up to 4 M spheres (include/collision_hip.h, col_collide_plan): the MSD sort
         # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
         # then take the LSD sort, and the MSD one is tried again after PLAN_RETRY calls (doubling up to

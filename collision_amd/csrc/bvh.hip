@@ -363,20 +363,28 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             }
         }
 
-        // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain
+        // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain.
+        // (Measured and not kept, round 2: a "pair walk" that fetches both children of a hit node together --
+        // their addresses follow from the parent's links -- and keeps hit children on a lane-indexed stack
+        // halves the chain of dependent loads per packet, but fetches 2 x 38 instead of 63 records: 0.112
+        // instead of 0.077 ms on the uniform 1 M scene, 1.22 instead of 0.86 ms on config 3.  The walk is
+        // bound by the NUMBER of record fetches that miss the scalar cache, not by their latency.)
         u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
         if (mode & 2) idx = END;
+        auto test = [&](const V4 &a, const V4 &b) -> u64 {
+            // Six lane masks ANDed as scalars: a '&&' chain makes hipcc fetch the record piecemeal behind
+            // branches, and the ballot of a combined bool costs a v_cndmask + v_cmp round trip.
+            return __builtin_amdgcn_ballot_w64(hx > a.x) & __builtin_amdgcn_ballot_w64(lx < b.x) &
+                   __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
+                   __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
+        };
         while (idx != END) {
             u32 li = idx;
             if (VEC) asm volatile("" : "+v"(li));               // vector load at a uniform address
             const V4 a = rows[2ull * li], b = rows[2ull * li + 1];
             const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
             const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
-            // Six lane masks ANDed as scalars: a '&&' chain makes hipcc fetch the record piecemeal behind
-            // branches, and the ballot of a combined bool costs a v_cndmask + v_cmp round trip.
-            const u64 hits = __builtin_amdgcn_ballot_w64(hx > a.x) & __builtin_amdgcn_ballot_w64(lx < b.x) &
-                             __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
-                             __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
+            const u64 hits = test(a, b);
             const bool is_leaf = idx >= leaf_start;
             if (STATS) {
                 trips++; leaf_tests += is_leaf;
@@ -606,14 +614,16 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     void *packed = p;
     int rc;
-    if (col_radix_tile(padded, 4, 4) == 1024) {
-        // small inputs are launch-bound: the Morton kernel folds the bounds partials itself and counts
-        // the sort's pass-0 digits (the histogram sits at the start of the sort scratch): two launches less
+    const uint32_t tile = col_radix_tile(padded, 4, 4);
+    if (tile == 1024 || tile == 4096) {
+        // Up to 16 Mi spheres the front end is fused: the Morton kernel folds the bounds partials itself and
+        // counts the digits of the sort's first pass (the histogram sits at the start of the sort scratch): two
+        // launches less.  The MSD plan (one global pass + an LDS finish per bucket) applies up to COL_MSD_MAX_N.
         uint32_t parts = 0;
-        const bool msd = sort_plan == COL_SORT_MSD;
+        const bool msd = sort_plan == COL_SORT_MSD && padded <= COL_MSD_MAX_N;
         if ((rc = col_minmax4_stage1(stream, coords, n, coord_bytes, red_scratch, &parts))) return rc;
         if ((rc = col_morton_tile(stream, coords, radii, red_scratch, parts, n, padded, coord_bytes, codes0, ids0, packed,
-                                  counter, (uint32_t *)sort_scratch, (uint32_t)col_ceil_div(padded, 1024), msd ? 22 : 0))) return rc;
+                                  counter, (uint32_t *)sort_scratch, tile, (uint32_t)col_ceil_div(padded, tile), msd ? 22 : 0))) return rc;
         if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;

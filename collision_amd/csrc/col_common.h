@@ -31,15 +31,19 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 //    [min row, max row] are left in `partials` (at most COL_MINMAX_PARTS of them);
 //  * col_morton_tile: col_morton_ex that folds those partials itself (no stage-2 launch) and also
 //    writes a histogram for the radix sort (digit = bits hist_shift..hist_shift+7: 0 for the LSD sort's
-//    pass 0, 22 for the MSD sort's bucket digit), tile = 1024 codes per block, digit-major
-//    hist[d * nblocks + b] like k_hist;
+//    pass 0, 22 for the MSD sort's bucket digit), `tile` = 1024 or 4096 codes per block (the sort's
+//    tile, col_radix_tile), digit-major hist[d * nblocks + b] like k_hist;
 //  * col_radix_sort_ex(have_hist0 = 1): col_radix_sort that finds the pass-0 histogram already at the
 //    start of `scratch`.
 #define COL_MINMAX_PARTS 256
+// col_radix_sort_msd: one workgroup finishes one of 256 top-digit buckets in LDS -- 8192 pairs per bucket for
+// inputs up to COL_MSD_SMALL_N codes, 16384 up to COL_MSD_MAX_N (uniform scenes: n / 256 per bucket +- 4 sigma)
+#define COL_MSD_SMALL_N 1900000u
+#define COL_MSD_MAX_N 4050000u
 extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                               uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks, int hist_shift);
+                               uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift);
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 

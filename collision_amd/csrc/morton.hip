@@ -61,28 +61,30 @@ __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coor
     if (ids) ids[i] = i;      // collision.cl:8-10
 }
 
-// The same codes, for col_collide's small-input path: one block per 1024-code tile of the radix sort.
+// The same codes, for col_collide's fused front end: one block per tile of the radix sort (1024 codes
+// below 1 Mi spheres, 4096 up to 16 Mi: col_radix_tile), 4 rows per thread.
 // The block folds the `parts` partial [min row, max row] results of the bounds reduction itself
 // (min/max are exact and order-independent, so every block gets the bits of a stage-2 launch), and
-// counts its tile's pass-0 digits in LDS while the codes are in registers.
-constexpr int MT_TILE = 1024;
-template <typename T>
-__global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__ coords, const T *__restrict__ partials,
-                                                      u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
-                                                      u32 *__restrict__ ids, const T *__restrict__ radii,
-                                                      Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
-                                                      u32 *__restrict__ hist0, u32 nblocks, int hist_shift) {
-    __shared__ T s_fold[4][8];
+// counts its tile's digits for the sort's first pass in LDS while the codes are in registers.
+constexpr int MT_ROWS = 4;
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ coords, const T *__restrict__ partials,
+                                                     u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
+                                                     u32 *__restrict__ ids, const T *__restrict__ radii,
+                                                     Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
+                                                     u32 *__restrict__ hist0, u32 nblocks, int hist_shift) {
+    constexpr int TILE = NT * MT_ROWS, NW = NT / 64;
+    __shared__ T s_fold[NW][8];
     __shared__ u32 s_hist[256];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (blockIdx.x == 0 && tid == 0 && zero_word) *zero_word = 0;
-    s_hist[tid] = 0;
+    if (tid < 256) s_hist[tid] = 0;
     // this thread's rows first: their loads overlap the fold of the partials below
-    Vec4<T> c[MT_TILE / 256];
-    T rad[MT_TILE / 256];
+    Vec4<T> c[MT_ROWS];
+    T rad[MT_ROWS];
 #pragma unroll
-    for (int k = 0; k < MT_TILE / 256; k++) {
-        const u32 i = blockIdx.x * MT_TILE + k * 256 + tid;
+    for (int k = 0; k < MT_ROWS; k++) {
+        const u32 i = blockIdx.x * TILE + k * NT + tid;
         if (i < n) {
             c[k] = coords[i];
             if (packed) rad[k] = radii[i];
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
     T acc[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { acc[k] = (T)INFINITY; acc[4 + k] = -(T)INFINITY; }
-    for (u32 i = tid; i < parts; i += 256) {
+    for (u32 i = tid; i < parts; i += NT) {
         const T *q = partials + (size_t)i * 8;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -118,8 +120,7 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
         T r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = s_fold[0][k];
-#pragma unroll
-        for (int ww = 1; ww < 4; ww++) {
+        for (int ww = 1; ww < NW; ww++) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 r[k] = s_fold[ww][k] < r[k] ? s_fold[ww][k] : r[k];
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
         mx.x = r[4]; mx.y = r[5]; mx.z = r[6]; mx.w = r[7];
     }
 #pragma unroll
-    for (int k = 0; k < MT_TILE / 256; k++) {
-        const u32 i = blockIdx.x * MT_TILE + k * 256 + tid;
+    for (int k = 0; k < MT_ROWS; k++) {
+        const u32 i = blockIdx.x * TILE + k * NT + tid;
         if (i >= padded) continue;
         u32 code = 0xFFFFFFFFu;   // collision.py:137-142
         if (i < n) {
@@ -148,7 +149,22 @@ __global__ __launch_bounds__(256) void k_morton_tile(const Vec4<T> *__restrict__
         atomicAdd(&s_hist[(code >> hist_shift) & 255u], 1u);
     }
     __syncthreads();
-    hist0[(uint64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
+    if (tid < 256) hist0[(uint64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
+}
+
+template <typename T>
+int launch_morton_tile(hipStream_t s, u32 tile, const void *coords, const void *radii, const void *partials, uint32_t parts,
+                       uint32_t n, uint32_t padded, uint32_t *codes, uint32_t *ids, void *packed, uint32_t *zero_word,
+                       uint32_t *hist0, uint32_t nblocks, int hist_shift) {
+    dim3 grid(nblocks);
+    if (tile == 1024)
+        k_morton_tile<T, 256><<<grid, dim3(256), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
+                                                          (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift);
+    else
+        k_morton_tile<T, 1024><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
+                                                            (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift);
+    COL_LAUNCH_OK();
+    return COL_OK;
 }
 
 }  // namespace
@@ -157,24 +173,19 @@ extern "C" {
 
 int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                     uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                    uint32_t *zero_word, uint32_t *hist0, uint32_t nblocks, int hist_shift) {
+                    uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift) {
     if (padded < n || parts == 0 || !hist0 || hist_shift < 0 || hist_shift > 24) return COL_EINVAL;
+    if (tile != 1024 && tile != 4096) return COL_EINVAL;
     if (padded == 0) return COL_OK;
     if (packed && !radii) return COL_EINVAL;
-    if (nblocks != (uint32_t)col_ceil_div(padded, MT_TILE)) return COL_EINVAL;
-    dim3 grid(nblocks), block(256);
+    if (nblocks != (uint32_t)col_ceil_div(padded, tile)) return COL_EINVAL;
     if (coord_bytes == 4)
-        k_morton_tile<float><<<grid, block, 0, col_stream(stream)>>>((const Vec4<float> *)coords, (const float *)partials, parts,
-                                                                     n, padded, codes, ids, (const float *)radii,
-                                                                     (Vec4<float> *)packed, zero_word, hist0, nblocks, hist_shift);
-    else if (coord_bytes == 8)
-        k_morton_tile<double><<<grid, block, 0, col_stream(stream)>>>((const Vec4<double> *)coords, (const double *)partials,
-                                                                      parts, n, padded, codes, ids, (const double *)radii,
-                                                                      (Vec4<double> *)packed, zero_word, hist0, nblocks, hist_shift);
-    else
-        return COL_EINVAL;
-    COL_LAUNCH_OK();
-    return COL_OK;
+        return launch_morton_tile<float>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
+                                         zero_word, hist0, nblocks, hist_shift);
+    if (coord_bytes == 8)
+        return launch_morton_tile<double>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
+                                          zero_word, hist0, nblocks, hist_shift);
+    return COL_EINVAL;
 }
 
 // col_morton plus two by-products for col_collide: packed (x, y, z, r) rows and a zeroed word.

@@ -358,14 +358,14 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 // replaces three global passes of three launches each.  A larger bucket (clustered codes) takes the
 // same three passes through global memory, chunk by chunk, by its one block: correct but slow, and
 // reported through *oversize so that the caller goes back to the LSD sort.
-constexpr int BS_NT = 1024, BS_IT = 8, BS_NW = BS_NT / COL_WAVE;
-constexpr u32 BS_CAP = BS_NT * BS_IT;          // 8192 pairs
+constexpr int BS_NT = 1024, BS_NW = BS_NT / COL_WAVE;
 constexpr int BS_SHIFT = 22;                   // bucket digit = bits 22..29 of a 30-bit Morton code (pads: 255)
-constexpr int BS_ROW = COL_WAVE * BS_IT;       // positions per wave
+// BS_IT items per thread: 8 -> buckets of up to 8192 pairs (73 KB of LDS, inputs below ~2 M codes),
+//                         16 -> 16384 pairs (145 KB: one workgroup per CU, inputs up to ~4 M codes)
 
-struct BucketLds {
-    u32 keys[BS_CAP];
-    u32 vals[BS_CAP];
+template <int BS_IT> struct BucketLds {
+    u32 keys[BS_NT * BS_IT];
+    u32 vals[BS_NT * BS_IT];
     u32 cnt[BS_NW][RDIG];
     u32 base[RDIG];
     u32 ws[BS_NW];
@@ -375,7 +375,8 @@ struct BucketLds {
 // this thread = w * row_len + k * 64 + lane (k * 64 < row_len); rows at or beyond `m` hold pads (key
 // 0xFFFFFFFF) and are skipped.  On return pos[k] = rank of the item inside its (wave, digit) group and lds.cnt[i][d] = number
 // of ranked items (pads of a partly valid row included) of wave i with digit d.
-__device__ __forceinline__ void bucket_rank(BucketLds &lds, const u32 (&key)[BS_IT], u32 (&pos)[BS_IT], u32 m, int shift,
+template <int BS_IT>
+__device__ __forceinline__ void bucket_rank(BucketLds<BS_IT> &lds, const u32 (&key)[BS_IT], u32 (&pos)[BS_IT], u32 m, int shift,
                                             u32 w, u32 tid, u32 row_len) {
     for (u32 i = tid; i < BS_NW * RDIG; i += BS_NT) (&lds.cnt[0][0])[i] = 0;
     __syncthreads();
@@ -393,10 +394,13 @@ __device__ __forceinline__ void bucket_rank(BucketLds &lds, const u32 (&key)[BS_
     __syncthreads();
 }
 
+template <int BS_IT>
 __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u32 *__restrict__ v_a, u32 *__restrict__ k_b,
                                                         u32 *__restrict__ v_b, u32 n, const u32 *__restrict__ offsets,
                                                         u32 nblocks, u32 *oversize) {
-    __shared__ BucketLds lds;
+    constexpr u32 BS_CAP = BS_NT * BS_IT;
+    constexpr int BS_ROW = COL_WAVE * BS_IT;       // positions per wave
+    __shared__ BucketLds<BS_IT> lds;
     const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1);
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid / COL_WAVE));
     const u32 d = blockIdx.x;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
             val[k] = ok ? v_a[start + p] : 0u;
         }
         for (int shift = 0; shift < BS_SHIFT; shift += 8) {
-            bucket_rank(lds, key, pos, S, shift, w, tid, L);
+            bucket_rank<BS_IT>(lds, key, pos, S, shift, w, tid, L);
             {   // exclusive over (digit, wave): digit `tid`
                 u32 c[BS_NW], tot = 0;
                 if (tid < RDIG) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
                 key[k] = p < m ? sk[c0 + p] : 0xFFFFFFFFu;
                 val[k] = p < m ? sv[c0 + p] : 0u;
             }
-            bucket_rank(lds, key, pos, m, shift, w, tid, (u32)BS_ROW);
+            bucket_rank<BS_IT>(lds, key, pos, m, shift, w, tid, (u32)BS_ROW);
             if (tid < RDIG) {
                 // this chunk's (wave, digit) groups start where the digit's running offset stands; pads (digit
                 // 255 in every pass, ranked after the real items of their row) do not advance it
@@ -753,18 +757,19 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
                : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass * 8, offsets);
 }
 
-// MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs
-// sorted with the 1024-pair tile.  The histogram of the bucket digit (bits 22..29, digit-major, one row
-// entry per 1024-pair tile) must already be at the start of `scratch` (col_morton_tile writes it).
+// MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs up to
+// COL_MSD_MAX_N pairs.  The histogram of the bucket digit (bits 22..29, digit-major, one row entry per tile
+// of col_radix_tile(n) pairs) must already be at the start of `scratch` (col_morton_tile writes it).
 // Same result as col_radix_sort.  *oversize (device-visible, may be NULL) receives the size of a bucket
 // that did not fit LDS, if any.
 int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
                        uint64_t n, void *scratch, uint32_t *oversize) {
     if (n == 0) return COL_OK;
     if (!scratch || !vals || !vals_out) return COL_EINVAL;
-    if (tile_auto(n, 4) != (u32)(NT_SMALL * IT_SMALL)) return COL_EINVAL;      // (a forced tile class does not apply here)
+    if (n > COL_MSD_MAX_N) return COL_EINVAL;
+    const u32 tile = tile_auto(n, 4);                     // (a forced tile class does not apply here)
     hipStream_t s = col_stream(stream);
-    const size_t nb = col_ceil_div(n, NT_SMALL * IT_SMALL);
+    const size_t nb = col_ceil_div(n, tile);
     char *p = (char *)scratch;
     u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
@@ -772,9 +777,14 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
     u32 *tmp_vals = (u32 *)p;
     int rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);
     if (rc) return rc;
-    rc = launch_scatter_it<u32, IT_SMALL, NT_SMALL>(s, keys, tmp_keys, vals, tmp_vals, n, 4, BS_SHIFT, hist);
+    if (tile == (u32)(NT_SMALL * IT_SMALL)) rc = launch_scatter_it<u32, IT_SMALL, NT_SMALL>(s, keys, tmp_keys, vals, tmp_vals, n, 4, BS_SHIFT, hist);
+    else rc = launch_scatter_it<u32, IT_BIG, NT_MID>(s, keys, tmp_keys, vals, tmp_vals, n, 4, BS_SHIFT, hist);
     if (rc) return rc;
-    k_bucket_sort<<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+    // a uniform scene puts n / 256 codes into a bucket: the 8192-pair finish up to ~1.9 M, the 16384-pair one above
+    if (n <= COL_MSD_SMALL_N)
+        k_bucket_sort<8><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+    else
+        k_bucket_sort<16><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -796,7 +806,7 @@ int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void
     u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
     void *tmp_keys = p;                p += align256((size_t)n * key_bytes);
-    void *tmp_vals = p;
+    void *tmp_vals = p;                // (carved for THIS n: never more than col_radix_scratch_bytes(n) in total)
     const int passes = key_bytes;      // 8-bit digits: 4 or 8 passes (even), so the last one lands in *_out
     const void *src_k = keys, *src_v = vals;
     for (int pass = 0; pass < passes; pass++) {

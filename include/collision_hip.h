@@ -198,16 +198,17 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
                 col_node *nodes, void *bounds, uint32_t *flags, void *scratch,
                 uint32_t *counter, uint32_t *pairs, uint32_t capacity);
 
-/* col_collide with a choice of sort for inputs below 1 Mi spheres (above, the plan is ignored):
+/* col_collide with a choice of sort for inputs of up to 4 000 000 spheres (above, the plan is ignored):
  *   COL_SORT_LSD  the four-pass LSD sort (what col_collide uses);
  *   COL_SORT_MSD  one global pass on the top 8 code bits, then every bucket finished inside one workgroup's
- *                 LDS -- 6 launches less.  Same outputs.  A bucket of more than 8192 pairs (clustered scenes)
+ *                 LDS -- 6 launches less.  Same outputs.  A bucket of more than 8192 pairs (16384 above 1.9 M
+ *                 spheres; clustered scenes)
  *                 is still sorted correctly but slowly, and its size is stored to *oversize (memory the
  *                 device can write, e.g. from col_host_alloc; may be NULL): the caller should then go back to
  *                 COL_SORT_LSD.  collision_amd.collision.Collider does that on its own. */
-/* The MSD plan's sort on its own: (u32 code, u32 id) pairs, codes 30-bit or the 0xFFFFFFFF pad, n below
- * 1 Mi.  The digit-major histogram of the bucket digit (bits 22..29) per 1024-code tile -- what the fused
- * Morton kernel leaves -- must be at the start of `scratch` (col_radix_scratch_bytes(n, 4, 4)). */
+/* The MSD plan's sort on its own: (u32 code, u32 id) pairs, codes 30-bit or the 0xFFFFFFFF pad, n up to
+ * 4 000 000.  The digit-major histogram of the bucket digit (bits 22..29) per col_radix_tile(n)-code tile --
+ * what the fused Morton kernel leaves -- must be at the start of `scratch` (col_radix_scratch_bytes(n, 4, 4)). */
 int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
                        uint32_t *vals_out, uint64_t n, void *scratch, uint32_t *oversize);
 #define COL_SORT_LSD 0

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from collision_amd.collision import NO_NODE, Collider
-from tests.util import collider_state, pad4, pair_set, run_collider
+from tests.util import assert_same_pair_set, collider_state, pad4, pair_set, run_collider
 
 pytestmark = pytest.mark.gpu
 
@@ -52,8 +52,7 @@ def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=
     np.testing.assert_array_equal(st["bounds"][:, :, :3], ref["bounds"][:, :, :3])
     assert count == ref["count"]
     if capacity is None or capacity >= count:
-        assert pair_set(pairs) == pair_set(ref["pairs"])       # same orientation, any order
-        assert len(pairs) == len(pair_set(pairs))
+        assert_same_pair_set(pairs, ref["pairs"])               # same orientation, any order, each once
     return collider, st, count, pairs
 
 
@@ -247,11 +246,12 @@ def test_three_million_spheres_match_oracle(oracle, hip_env):
 
 @pytest.mark.parametrize("plan", ["lsd", "msd"])
 @pytest.mark.parametrize("kind,n", [("uniform", 1000), ("uniform", 200000), ("uniform", 1000000), ("clustered", 150000),
-                                    ("identical", 20000)])
+                                    ("identical", 20000), ("uniform", 2000000), ("uniform", 4000000), ("clustered", 1500000)])
 def test_both_sort_plans_give_the_oracle_bits(oracle, hip_env, plan, kind, n):
-    """Below 1 Mi spheres col_collide_plan has two sorts (four LSD passes, or one MSD pass + a bucket
-    finish in LDS); clustered and identical centres put more than 8192 codes into one bucket, which the
-    MSD plan must still sort exactly (its slow path)."""
+    """Up to 4 M spheres col_collide_plan has two sorts (four LSD passes, or one MSD pass + a bucket
+    finish in LDS: 1024-pair tile and 8192-pair buckets below 1 Mi, 4096-pair tile above, 16384-pair
+    buckets above 1.9 M); clustered and identical centres put more codes into one bucket than fit, which
+    the MSD plan must still sort exactly (its slow path)."""
     if kind == "uniform":
         coords, radii = uniform_scene(n, 0.1 * n ** (-1.0 / 3.0), "float32")
     elif kind == "clustered":

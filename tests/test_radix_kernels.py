@@ -163,3 +163,39 @@ def test_msd_sort_bucket_sizes(hip_env, big):
     np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
     np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
     assert int(download(cq, flag, np.uint32, 1)[0]) == (big if big > 8192 else 0)
+
+
+@pytest.mark.parametrize("n_real,big", [(1200000, 8193), (1200000, 30000), (2500000, 16384), (2500000, 16385), (3900000, 100)])
+def test_msd_sort_middle_tile(hip_env, n_real, big):
+    """col_radix_sort_msd above 1 Mi codes: the global pass runs on the 4096-pair tile, and above 1.9 M codes
+    a bucket is finished in a 16384-pair LDS image (8192 below); larger buckets take the chunked path and are
+    reported.  Result = stable sort on all 32 bits."""
+    ctx, cq = hip_env
+    rs = np.random.RandomState(big)
+    pads = 333
+    low = rs.randint(0, 1 << 22, size=n_real, dtype=np.uint64)
+    low[::5] = low[1]
+    digit = rs.randint(0, 250, size=n_real).astype(np.uint64)
+    digit[digit == 5] = 6
+    digit[rs.choice(n_real, size=big, replace=False)] = 5          # bucket 5 holds exactly `big` codes
+    keys = np.concatenate([((digit << np.uint64(22)) | low).astype(np.uint32), np.full(pads, 0xFFFFFFFF, np.uint32)])
+    n = len(keys)
+    vals = np.arange(n, dtype=np.uint32)
+    tile = call.col_radix_tile(n, 4, 4)
+    assert tile == 4096
+    nb = -(-n // tile)
+    d8 = ((keys >> np.uint32(22)) & np.uint32(255)).astype(np.int64)
+    hist = np.zeros((256, nb), np.uint32)
+    np.add.at(hist, (d8, np.arange(n) // tile), 1)
+    scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, 4))
+    kb, vb = upload(ctx, keys), upload(ctx, vals)
+    ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+    flag = upload(ctx, np.zeros(1, np.uint32))
+    hip.write_buffer(cq, scratch, hist)
+    call.col_radix_sort_msd(cq.stream, kb.ptr, ko.ptr, vb.ptr, vo.ptr, n, scratch.ptr, flag.ptr)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(download(cq, ko, np.uint32, n), keys[order])
+    np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
+    cap = 8192 if n <= 1900000 else 16384
+    biggest = max(big, int(np.bincount(d8[:n_real], minlength=256).max()))
+    assert int(download(cq, flag, np.uint32, 1)[0]) == (big if big > cap else 0) or biggest > cap

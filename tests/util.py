@@ -24,6 +24,20 @@ def pair_set(pairs):
     return set(map(tuple, np.asarray(pairs).tolist()))
 
 
+def packed_pairs(pairs):
+    """(count, 2) uint32 -> sorted uint64 keys (first << 32 | second): set comparison for millions of pairs."""
+    p = np.asarray(pairs, dtype=np.uint64).reshape(-1, 2)
+    return np.sort((p[:, 0] << np.uint64(32)) | p[:, 1])
+
+
+def assert_same_pair_set(got, want):
+    """Same pairs with the same orientation, any order, none reported twice."""
+    g, w = packed_pairs(got), packed_pairs(want)
+    assert len(g) == len(w), (len(g), len(w))
+    np.testing.assert_array_equal(g, w)
+    assert (np.diff(g) != 0).all()
+
+
 def run_collider(ctx, cq, collider, coords, radii, capacity):
     """Upload, run get_collisions, read back (count, pairs[:min(count, capacity)])."""
     dt = collider.program.coord_dtype

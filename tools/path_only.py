@@ -1,4 +1,5 @@
-"""Runs only the 1 M-sphere path (config 2) a few times, for rocprofv3 passes."""
+"""Runs only the single-GPU path a few times, for rocprofv3 passes.
+    python tools/path_only.py [steps] [n_spheres] [plan: auto|lsd|msd] [scene: uniform|config3]"""
 import os
 import sys
 
@@ -10,11 +11,21 @@ from collision_amd.collision import Collider
 ctx = hip.Context()
 cq = hip.CommandQueue(ctx)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-coords, radii = bench.uniform_scene(bench.N_SPHERES)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.N_SPHERES
+plan = sys.argv[3] if len(sys.argv) > 3 else "auto"
+scene = sys.argv[4] if len(sys.argv) > 4 else "uniform"
+if scene == "config3":
+    coords, radii = bench.clustered_scene(n, 0.0152)
+    cap = 1 << 25
+else:
+    coords, radii = bench.uniform_scene(n)
+    radii[:] = bench.RADIUS * (1e6 / n) ** (1.0 / 3.0)
+    cap = bench.PAIR_CAPACITY * 8
 cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
-nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, bench.PAIR_CAPACITY * 8)
-col = Collider(ctx, bench.N_SPHERES, bench.NGROUPS, bench.GROUP_SIZE)
+nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
+col = Collider(ctx, n, bench.NGROUPS, bench.GROUP_SIZE)
+col.sort_plan = plan
 for _ in range(steps):
-    col.get_collisions(cq, cb, rb, nb, pb, bench.PAIR_CAPACITY)
+    col.get_collisions(cq, cb, rb, nb, pb, cap)
 cq.finish()
 print("pairs", int(hip.read_buffer(cq, nb, "uint32", 1)[0]))

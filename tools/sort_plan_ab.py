@@ -5,8 +5,15 @@ from collision_amd import hip
 from collision_amd.collision import Collider
 import bench
 ctx = hip.Context(); cq = hip.CommandQueue(ctx)
-n = 1000000
-for name, (coords, radii) in (("uniform", bench.uniform_scene(n)), ("config3", bench.clustered_scene(n, 0.0152))):
+def scenes():
+    yield "uniform 1M", bench.uniform_scene(1000000)
+    yield "config3 1M", bench.clustered_scene(1000000, 0.0152)
+    for m in (2000000, 4000000):
+        c, r = bench.uniform_scene(m)
+        r[:] = bench.RADIUS * (1e6 / m) ** (1.0 / 3.0)
+        yield "uniform %dM" % (m // 1000000), (c, r)
+for name, (coords, radii) in scenes():
+    n = len(coords)
     cap = 1 << 25
     cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
     nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)

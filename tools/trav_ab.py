@@ -16,7 +16,7 @@ def clustered(n, sigma, r, seed=4):
     return c, np.full(n, r, np.float32)
 
 scenes = [("uniform r=0.001",) + bench.uniform_scene(n)]
-for sigma in (0.05, 0.02):
+for sigma in (0.05, 0.02, 0.0152):
     scenes.append(("clustered sigma=%g r=0.001" % sigma,) + clustered(n, sigma, 0.001))
 cap = 1 << 26
 pb = hip.Buffer(ctx, cap * 8)
@@ -26,7 +26,7 @@ for name, coords, radii in scenes:
     cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
     col = Collider(ctx, n, 64, 256)
     col.get_collisions(cq, cb, rb, nb, pb, cap); cq.finish()
-    for variant in (0, 16, 0, 16):
+    for variant in (0, 32, 0, 32):      # 0 = pair walk (production), 32 = skip-chain walk (round 1)
         cdll().col_debug_traverse(variant)
         def run():
             call.col_fill(cq.stream, nb.ptr, z.ctypes.data, 4, 1)
