@@ -93,6 +93,13 @@ _PROTOS = {
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_fold_boxes": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "col_fold_boxes_strided": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_sample_rows": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_region_box": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "col_pack5_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
+                               C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_sample_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_splitters_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_digit_counts": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),

@@ -77,15 +77,27 @@ __global__ __launch_bounds__(256) void k_select_multi(const float4 *__restrict__
     }
 }
 
-// Pack the n_lists selection lists back to back into transport records; list sizes are read from
-// the device (counts), so the launch needs no host knowledge of them.  blockIdx.y = list.
+// Pack the n_lists selection lists into transport records; list sizes are read from the device
+// (counts), so the launch needs no host knowledge of them.  blockIdx.y = list.
+//   slot == 0: lists back to back.
+//   slot > 0:  list k goes to a fixed SLOT of 1 + slot records: a header record whose first word is the
+//              list's full length, then min(length, slot) records -- a fixed-size exchange carries the
+//              counts with the data, and the receiver sees from the header whether the slot overflowed.
 __global__ __launch_bounds__(256) void k_pack5_lists(const float4 *__restrict__ rows, const u32 *__restrict__ gids,
                                                       const u32 *__restrict__ lists, u32 stride,
-                                                      const u32 *__restrict__ counts, u32 *__restrict__ rec, u32 rec_capacity) {
+                                                      const u32 *__restrict__ counts, u32 *__restrict__ rec, u32 rec_capacity,
+                                                      u32 slot) {
     const u32 k = blockIdx.y;
-    const u32 cnt = counts[k];
+    u32 cnt = counts[k];
     u32 off = 0;
-    for (u32 j = 0; j < k; j++) off += counts[j];
+    if (slot) {
+        off = k * (slot + 1);
+        if (blockIdx.x == 0 && threadIdx.x < 5) rec[5ull * off + threadIdx.x] = threadIdx.x == 0 ? cnt : 0u;
+        off += 1;
+        cnt = min(cnt, slot);
+    } else {
+        for (u32 j = 0; j < k; j++) off += counts[j];
+    }
     for (u32 i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
         if (off + i >= rec_capacity) return;            // overflow is reported by the host from the counts
         const u32 s = lists[(uint64_t)k * stride + i];
@@ -141,11 +153,16 @@ __global__ __launch_bounds__(256) void k_select(const float4 *__restrict__ rows,
 
 // Lane-per-ghost walk from the root over the 32-byte records (box + skip/down links, bvh.hip).
 // No position pruning: every local leaf is a candidate for a ghost.
+// SLOTS: the ghosts are the transport records of a slotted exchange (k_pack5_lists, slot > 0): blockIdx.y =
+// slot, the slot's header gives its length; an overflowed slot is reported in flags[0] (largest length
+// seen), and flags[1] accumulates the number of ghosts.
 constexpr int GW = 4, GCAP = 256;
+template <bool SLOTS>
 __global__ __launch_bounds__(GW * 64) void k_ghost(const float4 *__restrict__ ghosts, const u32 *__restrict__ ghost_gids,
                                                    u32 n_ghost, const float4 *__restrict__ rows, u32 n,
                                                    const u32 *__restrict__ local_gids, u32 *__restrict__ pairs,
-                                                   u32 *__restrict__ counter, u32 capacity) {
+                                                   u32 *__restrict__ counter, u32 capacity, const u32 *__restrict__ rec,
+                                                   u32 slot, u32 *__restrict__ flags) {
     __shared__ uint2 s_buf[GW][GCAP];
     const u32 lane = lane_id(), w = threadIdx.x / 64;
     const u32 leaf_start = n - 1;
@@ -154,7 +171,22 @@ __global__ __launch_bounds__(GW * 64) void k_ghost(const float4 *__restrict__ gh
     const u32 g = blockIdx.x * (GW * 64) + threadIdx.x;
     float lx = INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;
     u32 gid = 0, idx = END;
-    if (g < n_ghost) {
+    if (SLOTS) {
+        const u32 *base = rec + 5ull * blockIdx.y * (slot + 1);
+        const u32 len = base[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0 && len) {
+            atomicMax(&flags[0], len);
+            atomicAdd(&flags[1], min(len, slot));
+        }
+        if (g < min(len, slot)) {
+            const u32 *o = base + 5ull * (1 + g);
+            const float cx = __uint_as_float(o[0]), cy = __uint_as_float(o[1]), cz = __uint_as_float(o[2]), cr = __uint_as_float(o[3]);
+            lx = cx - cr; ly = cy - cr; lz = cz - cr;                // same arithmetic as leafBounds, collision.cl:139-140
+            hx = cx + cr; hy = cy + cr; hz = cz + cr;
+            gid = o[4];
+            idx = 0;
+        }
+    } else if (g < n_ghost) {
         const float4 c = ghosts[g];
         lx = c.x - c.w; ly = c.y - c.w; lz = c.z - c.w;          // same arithmetic as leafBounds, collision.cl:139-140
         hx = c.x + c.w; hy = c.y + c.w; hz = c.z + c.w;
@@ -208,13 +240,13 @@ __global__ __launch_bounds__(256) void k_translate(u32 *__restrict__ pairs, cons
 
 // ---- small protocol steps (one launch each instead of chains of tensor-library calls) ----
 
-// fold `count` gathered [min row, max row] boxes into one
-__global__ __launch_bounds__(64) void k_fold_boxes(const float *__restrict__ boxes, u32 count, float *__restrict__ out) {
+// fold `count` gathered [min row, max row] boxes (`stride` floats apart) into one
+__global__ __launch_bounds__(64) void k_fold_boxes(const float *__restrict__ boxes, u32 count, u32 stride, float *__restrict__ out) {
     const u32 k = threadIdx.x;
     if (k >= 8) return;
     float acc = k < 4 ? INFINITY : -INFINITY;
     for (u32 i = 0; i < count; i++) {
-        const float v = boxes[8ull * i + k];
+        const float v = boxes[(u64)stride * i + k];
         acc = k < 4 ? (v < acc ? v : acc) : (v > acc ? v : acc);
     }
     out[k] = acc;
@@ -226,6 +258,23 @@ __global__ __launch_bounds__(256) void k_sample(const u32 *__restrict__ codes, u
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= samples) return;
     out[i] = n ? codes[samples > 1 ? (u32)(((u64)i * (n - 1)) / (samples - 1)) : 0u] : (1u << 30);
+}
+
+// `samples` evenly strided ROWS (x, y, z, r) of rows[0..n): what a rank contributes to the splitter
+// sample; an empty rank contributes rows at +infinity (their codes clamp to the ceiling)
+__global__ __launch_bounds__(256) void k_sample_rows(const float4 *__restrict__ rows, u32 n, u32 samples, float4 *__restrict__ out) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= samples) return;
+    out[i] = n ? rows[samples > 1 ? (u32)(((u64)i * (n - 1)) / (samples - 1)) : 0u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+}
+
+// [min row, max row] of (x, y, z, r) rows -> a box that contains every sphere: (min centre - max r,
+// max centre + max r).  Conservative (exact for equal radii), which is all a halo selection needs.
+__global__ __launch_bounds__(64) void k_region_box(const float *__restrict__ minmax, float *__restrict__ out) {
+    const u32 k = threadIdx.x;
+    if (k >= 8) return;
+    const float rmax = minmax[7];
+    out[k] = (k & 3) == 3 ? 0.f : (k < 4 ? minmax[k] - rmax : minmax[k] + rmax);
 }
 
 // world - 1 splitters = quantiles of the `count` gathered samples (count <= SPL_MAX): one block sorts
@@ -281,7 +330,25 @@ __global__ __launch_bounds__(256) void k_expand_counts(const u32 *__restrict__ c
 extern "C" {
 
 int col_fold_boxes(void *stream, const void *boxes, uint32_t count, void *out8) {
-    k_fold_boxes<<<dim3(1), dim3(64), 0, col_stream(stream)>>>((const float *)boxes, count, (float *)out8);
+    return col_fold_boxes_strided(stream, boxes, count, 8, out8);
+}
+
+int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_floats, void *out8) {
+    if (stride_floats < 8) return COL_EINVAL;
+    k_fold_boxes<<<dim3(1), dim3(64), 0, col_stream(stream)>>>((const float *)boxes, count, stride_floats, (float *)out8);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows) {
+    if (samples == 0) return COL_OK;
+    k_sample_rows<<<dim3((unsigned)col_ceil_div(samples, 256)), dim3(256), 0, col_stream(stream)>>>((const float4 *)rows, n, samples, (float4 *)out_rows);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_region_box(void *stream, const void *minmax8, void *out8) {
+    k_region_box<<<dim3(1), dim3(64), 0, col_stream(stream)>>>((const float *)minmax8, (float *)out8);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -358,11 +425,19 @@ int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const v
 
 int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
                     const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity) {
-    if (n_lists <= 0 || max_per_list == 0) return COL_OK;
+    return col_pack5_slots(stream, rows, gids, lists, stride, counts, n_lists, max_per_list, rec, rec_capacity, 0);
+}
+
+int col_pack5_slots(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
+                    const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity,
+                    uint32_t slot_records) {
+    if (n_lists <= 0) return COL_OK;
+    if (slot_records && (uint64_t)n_lists * (slot_records + 1) > rec_capacity) return COL_EINVAL;
+    if (max_per_list == 0) max_per_list = 1;           // (the slot headers are still written)
     unsigned gx = (unsigned)col_ceil_div(max_per_list, 256);
     if (gx > 1024) gx = 1024;
     k_pack5_lists<<<dim3(gx, (unsigned)n_lists), dim3(256), 0, col_stream(stream)>>>(
-        (const float4 *)rows, gids, lists, stride, counts, (u32 *)rec, rec_capacity);
+        (const float4 *)rows, gids, lists, stride, counts, (u32 *)rec, rec_capacity, slot_records);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -395,8 +470,20 @@ int col_traverse_ghost(void *stream, const void *ghost_rows, const uint32_t *gho
                        uint32_t *counter, uint32_t capacity) {
     if (n_ghost == 0 || n == 0) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    k_ghost<<<dim3((unsigned)col_ceil_div(n_ghost, GW * 64)), dim3(GW * 64), 0, col_stream(stream)>>>(
-        (const float4 *)ghost_rows, ghost_gids, n_ghost, (const float4 *)bounds, n, local_gids, pairs, counter, capacity);
+    k_ghost<false><<<dim3((unsigned)col_ceil_div(n_ghost, GW * 64)), dim3(GW * 64), 0, col_stream(stream)>>>(
+        (const float4 *)ghost_rows, ghost_gids, n_ghost, (const float4 *)bounds, n, local_gids, pairs, counter, capacity,
+        nullptr, 0, nullptr);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
+                             uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
+                             uint32_t *flags) {
+    if (n_slots == 0 || slot_records == 0 || n == 0) return COL_OK;
+    if ((capacity > 0 && !pairs) || !flags) return COL_EINVAL;
+    k_ghost<true><<<dim3((unsigned)col_ceil_div(slot_records, GW * 64), n_slots), dim3(GW * 64), 0, col_stream(stream)>>>(
+        nullptr, nullptr, 0, (const float4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -240,6 +240,18 @@ int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const v
 int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists,
                     uint32_t stride, const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec,
                     uint32_t rec_capacity);
+/* col_pack5_lists into fixed SLOTS of 1 + slot_records records: a header record (first word = the list's full
+ * length) followed by min(length, slot_records) records; slot_records == 0 is col_pack5_lists.  A fixed-size
+ * exchange of such slots needs no count exchange and no host sync; the receiver learns the lengths -- and an
+ * overflow -- from the headers. */
+int col_pack5_slots(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
+                    const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity,
+                    uint32_t slot_records);
+/* col_traverse_ghost over n_slots received slots; flags[0] = max(flags[0], longest header length),
+ * flags[1] += ghosts queried (2 x uint32, zeroed by the caller) */
+int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
+                             uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter,
+                             uint32_t capacity, uint32_t *flags);
 /* indices of rows whose box strictly overlaps aabb (2 x vec4) appended to out; *count zeroed by caller */
 int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out,
                        uint32_t *count);
@@ -259,6 +271,12 @@ int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, ui
  *   col_digit_counts   elements per digit from the scanned digit-major histogram of a radix pass
  *   col_expand_counts  out[peers[k]] = counts[k], 0 for the other ranks                        */
 int col_fold_boxes(void *stream, const void *boxes, uint32_t count, void *out8);
+/* the same with the boxes `stride_floats` apart (the tail of each rank's block of a larger all-gather) */
+int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_floats, void *out8);
+/* out_rows[i] = rows[i * (n - 1) / (samples - 1)]: a rank's contribution to the splitter sample (n == 0: rows at +inf) */
+int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows);
+/* [min row, max row] of (x, y, z, r) rows (col_reduce, MINMAX, width 4) -> box (min centre - max r, max centre + max r) */
+int col_region_box(void *stream, const void *minmax8, void *out8);
 int col_sample_u32(void *stream, const uint32_t *codes, uint32_t n, uint32_t samples, uint32_t *out);
 int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out);
 int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,

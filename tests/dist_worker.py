@@ -27,27 +27,25 @@ class OracleEngine(_protocol_ops()):
     """CPU stand-in for collision_amd.multi.HipEngine (same methods, torch CPU tensors); the small
     tensor steps between the collectives are ProtocolOps' tensor-library versions."""
 
-    def __init__(self, capacity, pair_capacity, ghost_capacity):
+    def __init__(self, capacity, pair_capacity):
+        import contextlib
         import torch
         import oracle
-        self.torch, self.oracle = torch, oracle
+        self.torch, self.oracle, self._null = torch, oracle, contextlib.nullcontext
         self.device = torch.device("cpu")
-        self.capacity, self.pair_capacity, self.ghost_capacity = capacity, pair_capacity, ghost_capacity
+        self.capacity, self.pair_capacity = capacity, pair_capacity
         z4 = lambda n: torch.zeros((n, 4), dtype=torch.float32)
         zi = lambda n: torch.zeros(n, dtype=torch.int32)
+        self._z5 = lambda n: torch.zeros((n, 5), dtype=torch.int32)
         self.rows_in, self.gids_in = z4(capacity), zi(capacity)
-        z5 = lambda n: torch.zeros((n, 5), dtype=torch.int32)
-        self.send5, self.recv5 = z5(capacity), z5(capacity)
+        self.send5, self.recv5 = self._z5(capacity), self._z5(capacity)
         self.owned_rows, self.owned_gids = z4(capacity), zi(capacity)
         self.radii = torch.zeros(capacity)
-        self.halo5, self.ghost5 = z5(ghost_capacity), z5(ghost_capacity)
-        self.ghost_rows, self.ghost_gids = z4(ghost_capacity), zi(ghost_capacity)
-        self.codes_sorted, self.perm = zi(capacity), zi(capacity)
-        self.max_peers = 8
-        self.sel_lists = zi(self.max_peers * capacity)
+        self.halo_send = self.halo_recv = None
+        self.perm = zi(capacity)
         self.found = []
         self.n_owned = 0
-        self._boxes = None
+        self._longest = self._ghosts = 0
 
     def load(self, coords4, radii, gids):
         n = len(coords4)
@@ -57,26 +55,37 @@ class OracleEngine(_protocol_ops()):
         self.gids_in[:n] = self.torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32))
         return n
 
-    def centre_range(self, rows, n):
-        t = self.torch
-        if n == 0:
-            return t.tensor([np.inf] * 4 + [-np.inf] * 4, dtype=t.float32)
-        return t.cat([rows[:n].min(dim=0).values, rows[:n].max(dim=0).values])
+    def begin_step(self):
+        self._longest = self._ghosts = 0
+
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
+    def halo_stream(self):
+        return self._null()
+
+    def codes_of_rows(self, rows, range8):
+        codes = self.oracle.morton(rows.numpy().copy(), range8.numpy().reshape(2, 4))
+        return self.torch.from_numpy(codes.view(np.int32).copy())
 
     def codes_of(self, rows, n, range8):
-        codes = self.oracle.morton(rows[:n].numpy(), range8.numpy().reshape(2, 4))
         self.codes = self.torch.zeros(self.capacity, dtype=self.torch.int32)
-        self.codes[:n] = self.torch.from_numpy(codes.view(np.int32))
+        self.codes[:n] = self.codes_of_rows(rows[:n], range8)
         return self.codes
 
-    def group_by_owner(self, codes, n, splitters):
+    def owner_counts_of(self, codes, n, splitters):
         c = codes[:n].numpy().view(np.uint32)
         sp = splitters.numpy().view(np.uint32)
-        dest = np.searchsorted(sp, c, side="right")
-        perm = np.argsort(dest, kind="stable")
+        self._dest = np.searchsorted(sp, c, side="right")
+        return self.torch.from_numpy(np.bincount(self._dest, minlength=len(sp) + 1).astype(np.int32))
+
+    def finish_grouping(self, n):
+        perm = np.argsort(self._dest, kind="stable")
         self.perm[:n] = self.torch.from_numpy(perm.astype(np.int32))
-        counts = np.bincount(dest, minlength=len(sp) + 1).astype(np.int32)
-        return self.perm, self.torch.from_numpy(counts)
+        return self.perm
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         t = self.torch
@@ -103,42 +112,48 @@ class OracleEngine(_protocol_ops()):
         self._lo = (self._rows[:, :3] - radii[:, None]).astype(np.float32)
         self._hi = (self._rows[:, :3] + radii[:, None]).astype(np.float32)
 
-    def region_box(self):
-        t = self.torch
-        if self.n_owned == 0:
-            return t.tensor([np.inf] * 4 + [-np.inf] * 4, dtype=t.float32)
-        lo, hi = self._lo.min(axis=0), self._hi.max(axis=0)
-        return t.tensor([lo[0], lo[1], lo[2], 0, hi[0], hi[1], hi[2], 0], dtype=t.float32)
+    def ensure_slots(self, slot, n_out, n_in):
+        want_s, want_r = max(1, n_out) * (slot + 1), max(1, n_in) * (slot + 1)
+        if self.halo_send is None or self.halo_send.shape[0] != want_s:
+            self.halo_send = self._z5(want_s)
+        if self.halo_recv is None or self.halo_recv.shape[0] != want_r:
+            self.halo_recv = self._z5(want_r)
 
-    def select_multi(self, rows, n, boxes_dev, peers):
+    def select_and_pack(self, rows, gids, n, boxes_dev, peers, slot):
         t = self.torch
-        counts = t.zeros(self.max_peers, dtype=t.int32)
         boxes = boxes_dev.numpy()
+        r = rows[:n].numpy()
+        lo, hi = r[:, :3] - r[:, 3:4], r[:, :3] + r[:, 3:4]
         for k, q in enumerate(peers):
             b = boxes[q]
-            hit = ((self._hi > b[0:3]) & (self._lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
-            idx = np.nonzero(hit)[0].astype(np.int32)
-            self.sel_lists[k * self.capacity:k * self.capacity + len(idx)] = t.from_numpy(idx)
-            counts[k] = len(idx)
-        return self.sel_lists, self.capacity, counts
+            hit = ((hi > b[0:3]) & (lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
+            idx = t.from_numpy(np.nonzero(hit)[0].astype(np.int32))
+            self._longest = max(self._longest, len(idx))
+            base = k * (slot + 1)
+            self.halo_send[base] = 0
+            self.halo_send[base, 0] = len(idx)
+            self.pack5(rows, gids, idx, 0, min(len(idx), slot), self.halo_send, base + 1)
 
-    def pack5_lists(self, rows, gids, lists, stride, counts_dev, n_lists, n, out5):
-        off = 0
-        for k in range(n_lists):
-            c = int(counts_dev[k])
-            self.pack5(rows, gids, lists, k * stride, c, out5, off)
-            off += c
+    def ghost_queries(self, n_in, slot, owned_gids):
+        for k in range(n_in):
+            base = k * (slot + 1)
+            length = int(self.halo_recv[base, 0])
+            self._longest = max(self._longest, length)
+            cnt = min(length, slot)
+            if self.n_owned == 0 or cnt == 0:
+                continue
+            rec = self.halo_recv[base + 1:base + 1 + cnt]
+            g = rec[:, :4].contiguous().view(self.torch.float32).numpy()
+            glo = (g[:, :3] - g[:, 3:4]).astype(np.float32)
+            ghi = (g[:, :3] + g[:, 3:4]).astype(np.float32)
+            gg = rec[:, 4].numpy().view(np.uint32)
+            self._ghosts += cnt
+            for i in range(cnt):
+                hit = ((ghi[i] > self._lo) & (glo[i] < self._hi)).all(axis=1)
+                self.found += [(int(gg[i]), int(self._gids[j])) for j in np.nonzero(hit)[0]]
 
-    def ghost_queries(self, rows, gids, n_ghost, owned_gids):
-        if self.n_owned == 0 or n_ghost == 0:
-            return
-        g = rows[:n_ghost].numpy()
-        glo = (g[:, :3] - g[:, 3:4]).astype(np.float32)
-        ghi = (g[:, :3] + g[:, 3:4]).astype(np.float32)
-        gg = gids[:n_ghost].numpy().view(np.uint32)
-        for k in range(n_ghost):
-            hit = ((ghi[k] > self._lo) & (glo[k] < self._hi)).all(axis=1)
-            self.found += [(int(gg[k]), int(self._gids[j])) for j in np.nonzero(hit)[0]]
+    def halo_stats(self):
+        return self._longest, self._ghosts
 
     def pair_count(self):
         return len(self.found)
@@ -205,6 +220,7 @@ def hip_read(cq, buf, dtype, shape):
 def main():
     mode, partition, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
+    halo_slot = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
     import torch  # noqa: F401
     import torch.distributed as dist
     dist.init_process_group("gloo")
@@ -218,10 +234,11 @@ def main():
     ctx = hip.Context(0)
     engine = None
     if mode == "cpu":
-        cap = 2 * n + 64
-        engine = OracleEngine(cap, 1 << 20, cap * world)
+        from collision_amd.misc import roundUp
+        cap = roundUp(int(int(mine.sum()) * 3.0) + 4096, 2 * 64)     # as DistributedCollider sizes it (slack 3)
+        engine = OracleEngine(cap, 1 << 20)
     dc = DistributedCollider(ctx, dist, int(mine.sum()), group_size=64, pair_capacity=1 << 22, partition=partition,
-                             slack=3.0, engine=engine)
+                             slack=3.0, engine=engine, halo_slot=halo_slot)
     dc.set_local_spheres(coords[mine], radii[mine], gids[mine])
     for _ in range(2):                       # twice: buffers are reused across steps
         dc.step()
@@ -229,6 +246,7 @@ def main():
     pairs = dc.local_pairs()
     total = dc.global_pair_count()
     stats = dict(dc.stats)
+    stats["repeats"] = dc.repeats
     if mode == "gpu":
         stats["rank_parity"] = per_rank_parity(dc)
     gathered = [None] * world
