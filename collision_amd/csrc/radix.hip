@@ -702,10 +702,42 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
     return COL_EINVAL;
 }
 
+// Value widths the scatter kernel moves itself; 1 / 2 / 64 / 128-byte values (the reference specialises for
+// any NumPy dtype, radix.py:16-25: uint8 ... (float64, 16)) are sorted as (key, index) pairs and gathered
+// once at the end (wide_value below).
+inline bool native_value(int val_bytes) { return val_bytes == 0 || val_bytes == 4 || val_bytes == 8 || val_bytes == 16 || val_bytes == 32; }
+inline bool wide_value(int val_bytes) { return val_bytes == 1 || val_bytes == 2 || val_bytes == 64 || val_bytes == 128; }
 inline bool bad_sizes(uint64_t n, int key_bytes, int val_bytes) {
     if (key_bytes != 4 && key_bytes != 8) return true;
-    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8 && val_bytes != 16 && val_bytes != 32) return true;
+    if (!native_value(val_bytes)) return true;
     return n >= 0xFFFFFFFFull;   // offsets are uint32 (as in the reference)
+}
+
+__global__ __launch_bounds__(256) void k_iota(u32 *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (u32)i;
+}
+// out[i] = in[idx[i]] for elements of CH chunks of type X (CH * sizeof(X) bytes): one chunk per thread
+template <typename X, int CH>
+__global__ __launch_bounds__(256) void k_gather_chunks(const X *__restrict__ in, const u32 *__restrict__ idx, X *__restrict__ out, uint64_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i = t / CH;
+    if (i >= n) return;
+    const u32 c = (u32)(t % CH);
+    out[i * CH + c] = in[(uint64_t)idx[i] * CH + c];
+}
+int gather_values(hipStream_t s, const void *in, const u32 *idx, void *out, uint64_t n, int val_bytes) {
+    const int ch = val_bytes >= 16 ? val_bytes / 16 : 1;
+    dim3 grid((unsigned)col_ceil_div(n * ch, 256)), block(256);
+    switch (val_bytes) {
+    case 1: k_gather_chunks<uint8_t, 1><<<grid, block, 0, s>>>((const uint8_t *)in, idx, (uint8_t *)out, n); break;
+    case 2: k_gather_chunks<uint16_t, 1><<<grid, block, 0, s>>>((const uint16_t *)in, idx, (uint16_t *)out, n); break;
+    case 64: k_gather_chunks<uint4, 4><<<grid, block, 0, s>>>((const uint4 *)in, idx, (uint4 *)out, n); break;
+    case 128: k_gather_chunks<uint4, 8><<<grid, block, 0, s>>>((const uint4 *)in, idx, (uint4 *)out, n); break;
+    default: return COL_EINVAL;
+    }
+    COL_LAUNCH_OK();
+    return COL_OK;
 }
 
 }  // namespace
@@ -732,6 +764,8 @@ uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)val_by
 // Monotone in n: sized for the largest histogram any n' <= n can need (see max_tiles_upto), so a scratch
 // buffer sized for n serves every smaller sort / col_collide call as well.
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
+    if (wide_value(val_bytes))       // (key, index) sort + the index ramp and its sorted image
+        return col_radix_scratch_bytes(n, key_bytes, 4) + 2 * align256((size_t)n * 4);
     const size_t nb = max_tiles_upto(n, key_bytes);
     const size_t hist = align256((size_t)RDIG * nb * sizeof(u32));
     return hist + align256(col_scan_scratch_bytes((uint64_t)RDIG * nb)) + align256((size_t)n * key_bytes) +
@@ -797,6 +831,25 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
 int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                       uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0) {
     if (!vals || !vals_out) val_bytes = 0;
+    if (wide_value(val_bytes)) {
+        // values of a width the scatter kernel does not move: sort (key, index), gather the values once
+        if (n >= 0xFFFFFFFFull || (key_bytes != 4 && key_bytes != 8)) return COL_EINVAL;
+        if (n == 0) return COL_OK;
+        if (!scratch) return COL_ENOSCRATCH;
+        hipStream_t s = col_stream(stream);
+        char *q = (char *)scratch + col_radix_scratch_bytes(n, key_bytes, 4);
+        u32 *iota = (u32 *)q, *sorted_idx = (u32 *)(q + align256((size_t)n * 4));
+        k_iota<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, s>>>(iota, n);
+        COL_LAUNCH_OK();
+        int rc = col_radix_sort_ex(stream, keys, keys_out, iota, sorted_idx, n, key_bytes, 4, scratch, 0, 0);
+        if (rc) return rc;
+        if ((rc = gather_values(s, vals, sorted_idx, vals_out, n, val_bytes))) return rc;
+        if (copy_back) {
+            COL_HIP(hipMemcpyAsync((void *)keys, keys_out, (size_t)n * key_bytes, hipMemcpyDeviceToDevice, s));
+            COL_HIP(hipMemcpyAsync((void *)vals, vals_out, (size_t)n * val_bytes, hipMemcpyDeviceToDevice, s));
+        }
+        return COL_OK;
+    }
     if (bad_sizes(n, key_bytes, val_bytes)) return COL_EINVAL;
     if (n == 0) return COL_OK;
     if (!scratch) return COL_ENOSCRATCH;

@@ -147,6 +147,108 @@ int by_op(void *stream, const void *values, uint64_t n, int width, int op, void 
     return COL_EINVAL;
 }
 
+// ---- generic accumulator lists (reduce.py:9-22 renders any list of (init, fn) pairs into reduce.cl) ----
+// Table-driven instead of rendered: up to COL_REDUCE_MAX_ACC accumulators, each an op code
+// (COL_ACC_MIN / MAX / ADD / MUL -- the binary functions the template can name: min, max, fmin, fmax, the
+// ADD macro, and MUL as its obvious sibling) and an initial value.  Output: one row of `width` scalars per
+// accumulator, in list order (ACC_SIZE consecutive VALDTYPEs, reduce.cl:34-37).  HBM-bound like the two
+// compiled-in lists; the op dispatch is a wave-uniform switch.
+struct AccList { int n; int op[COL_REDUCE_MAX_ACC]; double init[COL_REDUCE_MAX_ACC]; };
+
+template <typename T> __device__ __forceinline__ T init_value(double v) {
+    if (v == (double)INFINITY) return pos_inf<T>();
+    if (v == -(double)INFINITY) return neg_inf<T>();
+    return (T)v;
+}
+template <typename T> __device__ __forceinline__ T apply_op(int op, T a, T b) {
+    switch (op) {
+    case COL_ACC_MIN: return b < a ? b : a;
+    case COL_ACC_MAX: return b > a ? b : a;
+    case COL_ACC_MUL: return a * b;
+    default: return a + b;
+    }
+}
+
+template <typename T, int W>
+__device__ __forceinline__ void fold_list(const AccList &L, T (&a)[COL_REDUCE_MAX_ACC][W], T *out) {
+    __shared__ T s[(RT / COL_WAVE) * COL_REDUCE_MAX_ACC * W];
+    const u32 lane = lane_id(), w = threadIdx.x / COL_WAVE;
+    for (int k = 0; k < L.n; k++) {
+#pragma unroll
+        for (int o = COL_WAVE / 2; o > 0; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < W; i++) a[k][i] = apply_op(L.op[k], a[k][i], shfl_xor_t(a[k][i], o));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < W; i++) s[(w * COL_REDUCE_MAX_ACC + k) * W + i] = a[k][i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < L.n; k++) {
+            for (int i = 0; i < W; i++) {
+                T v = a[k][i];
+                for (int ww = 1; ww < RT / COL_WAVE; ww++) v = apply_op(L.op[k], v, s[(ww * COL_REDUCE_MAX_ACC + k) * W + i]);
+                out[k * W + i] = v;
+            }
+        }
+    }
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(RT) void k_reduce_list1(const Row<T, W> *__restrict__ rows, uint64_t n, AccList L, T *partials) {
+    T a[COL_REDUCE_MAX_ACC][W];
+    for (int k = 0; k < COL_REDUCE_MAX_ACC; k++)
+#pragma unroll
+        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(k < L.n ? L.init[k] : 0.0);
+    const uint64_t stride = (uint64_t)gridDim.x * RT;
+    for (uint64_t i = (uint64_t)blockIdx.x * RT + threadIdx.x; i < n; i += stride) {
+        const Row<T, W> r = rows[i];
+        for (int k = 0; k < L.n; k++)
+#pragma unroll
+            for (int c = 0; c < W; c++) a[k][c] = apply_op(L.op[k], a[k][c], r.v[c]);
+    }
+    fold_list<T, W>(L, a, partials + (size_t)blockIdx.x * L.n * W);
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(RT) void k_reduce_list2(const T *partials, uint32_t nparts, AccList L, T *out) {
+    T a[COL_REDUCE_MAX_ACC][W];
+    for (int k = 0; k < COL_REDUCE_MAX_ACC; k++)
+#pragma unroll
+        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(k < L.n ? L.init[k] : 0.0);
+    for (uint32_t p = threadIdx.x; p < nparts; p += RT)
+        for (int k = 0; k < L.n; k++)
+#pragma unroll
+            for (int c = 0; c < W; c++) a[k][c] = apply_op(L.op[k], a[k][c], partials[((size_t)p * L.n + k) * W + c]);
+    fold_list<T, W>(L, a, out);
+}
+
+template <typename T, int W>
+int launch_list(void *stream, const void *values, uint64_t n, const AccList &L, void *scratch, void *out) {
+    uint64_t blocks = col_ceil_div(n, (uint64_t)RT * 4);
+    if (blocks > RMAX_BLOCKS) blocks = RMAX_BLOCKS;
+    if (blocks == 0) blocks = 1;
+    k_reduce_list1<T, W><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>((const Row<T, W> *)values, n, L, (T *)scratch);
+    COL_LAUNCH_OK();
+    k_reduce_list2<T, W><<<dim3(1), dim3(RT), 0, col_stream(stream)>>>((const T *)scratch, (uint32_t)blocks, L, (T *)out);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+template <typename T>
+int list_by_width(void *stream, const void *values, uint64_t n, int width, const AccList &L, void *scratch, void *out) {
+    switch (width) {
+    case 1: return launch_list<T, 1>(stream, values, n, L, scratch, out);
+    case 2: return launch_list<T, 2>(stream, values, n, L, scratch, out);
+    case 4: return launch_list<T, 4>(stream, values, n, L, scratch, out);
+    case 8: return launch_list<T, 8>(stream, values, n, L, scratch, out);
+    case 16: return launch_list<T, 16>(stream, values, n, L, scratch, out);
+    default: return COL_EINVAL;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -170,7 +272,29 @@ int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_byt
 
 size_t col_reduce_scratch_bytes(int dtype, int width) {
     size_t eb = (dtype == COL_F32 || dtype == COL_U32 || dtype == COL_I32) ? 4 : 8;
-    return (size_t)RMAX_BLOCKS * 2 * (size_t)width * eb;
+    return (size_t)RMAX_BLOCKS * COL_REDUCE_MAX_ACC * (size_t)width * eb;
+}
+
+int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int width, int n_acc, const int *ops,
+                    const double *inits, void *scratch, void *out) {
+    if (!scratch) return COL_ENOSCRATCH;
+    if (n_acc < 1 || n_acc > COL_REDUCE_MAX_ACC || !ops || !inits) return COL_EINVAL;
+    AccList L;
+    L.n = n_acc;
+    for (int k = 0; k < COL_REDUCE_MAX_ACC; k++) {
+        L.op[k] = k < n_acc ? ops[k] : COL_ACC_ADD;
+        L.init[k] = k < n_acc ? inits[k] : 0.0;
+        if (L.op[k] < COL_ACC_MIN || L.op[k] > COL_ACC_MUL) return COL_EINVAL;
+    }
+    switch (dtype) {
+    case COL_F32: return list_by_width<float>(stream, values, n, width, L, scratch, out);
+    case COL_F64: return list_by_width<double>(stream, values, n, width, L, scratch, out);
+    case COL_U32: return list_by_width<uint32_t>(stream, values, n, width, L, scratch, out);
+    case COL_I32: return list_by_width<int32_t>(stream, values, n, width, L, scratch, out);
+    case COL_U64: return list_by_width<uint64_t>(stream, values, n, width, L, scratch, out);
+    case COL_I64: return list_by_width<int64_t>(stream, values, n, width, L, scratch, out);
+    default: return COL_EINVAL;
+    }
 }
 
 int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int width, int op,

@@ -20,7 +20,7 @@ from .scan import PrefixScanProgram, PrefixScanner  # noqa: F401  (re-exported)
 
 _UNSIGNED = {np.dtype(name) for name in np_unsigned_dtypes}
 _KEY_BYTES = (4, 8)
-_VALUE_BYTES = (4, 8, 16, 32)
+_VALUE_BYTES = (1, 2, 4, 8, 16, 32, 64, 128)     # 1 / 2 / 64 / 128: sorted as (key, index), gathered once
 
 
 def _value_bytes(value_dtype):

@@ -3,10 +3,15 @@
 Mirrors ``collision/reduce.py`` (ReductionProgram :9-22, Reducer :24-76).  The reference renders
 its kernel from a Jinja2 template with a list of ``(init, fn)`` accumulators; here the two
 accumulator lists the package uses are compiled in (``COL_OP_MINMAX`` for bounds.py:5,
-``COL_OP_SUM`` for summer.py:5) and a subclass names one through ``accumulator``.
+``COL_OP_SUM`` for summer.py:5) and any other list of up to four accumulators goes through the
+table-driven ``col_reduce_list`` -- ``fn`` one of ``min`` / ``max`` / ``fmin`` / ``fmax`` / ``ADD`` /
+``MUL`` (the binary functions the template can name), ``init`` a number or ``[-]INFINITY``.  A
+subclass names its list through ``accumulator``.
 ``ngroups`` / ``group_size`` are accepted for API parity; the launch geometry is the kernel's own
 (csrc/reduce.hip) and, unlike reduce.cl:40-52, every partial is folded whatever ``ngroups`` is.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import hip
@@ -19,15 +24,33 @@ _OPS = {
 }
 
 
+_ACC_FN = {"min": 0, "fmin": 0, "max": 1, "fmax": 1, "ADD": 2, "MUL": 3}
+MAX_ACCUMULATORS = 4
+
+
+def _parse_init(text):
+    text = str(text).strip().replace("(", "").replace(")", "")
+    if text in ("INFINITY", "+INFINITY"):
+        return float("inf")
+    if text == "-INFINITY":
+        return float("-inf")
+    return float(text)            # ValueError for anything that is not a number
+
+
 class ReductionProgram(ProgramHandle):
     accumulator = None      # set by subclasses, as in the reference (bounds.py:5, summer.py:5)
 
     def __init__(self, ctx, value_dtype):
         self.value_dtype = np.dtype(value_dtype)
         key = tuple(tuple(a) for a in (self.accumulator or ()))
-        if key not in _OPS:
+        if not key:
             raise ValueError("Unsupported accumulator list: {}".format(self.accumulator))
-        self.op = _OPS[key]
+        self.op = _OPS.get(key)
+        if self.op is None:       # not one of the compiled-in lists: the table-driven reducer
+            if len(key) > MAX_ACCUMULATORS or any(fn not in _ACC_FN for _, fn in key):
+                raise ValueError("Unsupported accumulator list: {}".format(self.accumulator))
+            self.acc_ops = (C.c_int * len(key))(*[_ACC_FN[fn] for _, fn in key])
+            self.acc_inits = (C.c_double * len(key))(*[_parse_init(init) for init, _ in key])
         self.acc_dtype = np.dtype((self.value_dtype, len(key)))
         self.type_code = type_code(self.value_dtype)
         self.width = device_width(self.value_dtype)
@@ -63,8 +86,12 @@ class Reducer:
         if self._scratch is None:
             self._scratch = hip.Buffer(p.context, call.col_reduce_scratch_bytes(p.type_code, p.width))
         cq.wait_for(wait_for)
-        call.col_reduce(cq.stream, values_buf.ptr, size, p.type_code, p.width, p.op,
-                        self._scratch.ptr, output_buf.ptr)
+        if p.op is not None:
+            call.col_reduce(cq.stream, values_buf.ptr, size, p.type_code, p.width, p.op,
+                            self._scratch.ptr, output_buf.ptr)
+        else:
+            call.col_reduce_list(cq.stream, values_buf.ptr, size, p.type_code, p.width, len(p.acc_ops), p.acc_ops,
+                                 p.acc_inits, self._scratch.ptr, output_buf.ptr)
         return hip.Event(cq)
 
 

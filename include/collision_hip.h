@@ -92,6 +92,16 @@ int col_event_elapsed_ms(float *ms, void *start, void *stop);
 size_t col_reduce_scratch_bytes(int dtype, int width);
 int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int width, int op,
                void *scratch, void *out);
+/* Any accumulator list (collision/reduce.py:9-22 renders a list of (init, fn) pairs into reduce.cl): n_acc <=
+ * COL_REDUCE_MAX_ACC accumulators, ops[k] one of COL_ACC_*, inits[k] the initial value (+-INFINITY = the
+ * type's extreme).  out: n_acc rows of `width` scalars, in list order (reduce.cl:34-37). */
+#define COL_REDUCE_MAX_ACC 4
+#define COL_ACC_MIN 0
+#define COL_ACC_MAX 1
+#define COL_ACC_ADD 2
+#define COL_ACC_MUL 3
+int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int width, int n_acc, const int *ops,
+                    const double *inits, void *scratch, void *out);
 
 /* ---------------------------------------------------------------- morton
  * Replaces the `range` kernel, the padding fill and `calculateCodes`
@@ -114,7 +124,8 @@ int col_block_scan(void *stream, uint32_t *data, uint64_t n, uint32_t block, con
 
 /* ---------------------------------------------------------------- radix sort
  * Replaces RadixSorter.sort (collision/radix.py:118-170): stable LSD sort of
- * n keys (key_bytes 4|8) with optional values (val_bytes 0|4|8|16|32) over
+ * n keys (key_bytes 4|8) with optional values (val_bytes 0|4|8|16|32 moved by
+ * the scatter passes; 1|2|64|128 sorted as (key, index) and gathered once) over
  * all key bits.  Result in keys_out/vals_out; keys/vals are left untouched
  * unless copy_back != 0, which also leaves a sorted copy there as the
  * reference does (radix.py:158-169).

@@ -69,3 +69,49 @@ def test_summer(hip_env, value_dtype):
     if value_dtype.shape == (3,):
         out, expected = out[:3], expected[:3]
     np.testing.assert_equal(out.reshape(-1), np.asarray(expected).reshape(-1))
+
+
+@pytest.mark.parametrize("value_dtype", [np.dtype("float32"), np.dtype(("float64", 4)), np.dtype(("int32", 2)), np.dtype("uint64")], ids=str)
+def test_generic_accumulator_lists(hip_env, value_dtype):
+    """reduce.py:9-22 renders ANY list of (init, fn) accumulators into its kernel template; beyond the two
+    lists the package itself uses (Bounds, Summer) that is the table-driven col_reduce_list: here
+    [sum, min, max, product-of-ones] in one pass, each accumulator one output row (reduce.cl:34-37)."""
+    from collision_amd.reduce import ReductionProgram, Reducer
+    ctx, cq = hip_env
+    vd = _device_dtype(value_dtype)
+
+    class StatsProgram(ReductionProgram):
+        accumulator = [("0", "ADD"), ("INFINITY", "fmin" if vd.base.kind == "f" else "min"), ("-INFINITY", "max"), ("1", "MUL")]
+
+    class Stats(Reducer):
+        program_type = StatsProgram
+
+    rs = np.random.RandomState(4)
+    n = 100003
+    values = rs.randint(1, 16, size=(n,) + vd.shape).astype(vd.base)           # small integers: float32 sums stay exact
+    ones = np.ones_like(values)
+    for data, prod in ((values, None), (ones, 1)):
+        out_buf = hip.Buffer(ctx, 4 * dtype_sizeof(value_dtype))
+        e = Stats(ctx, 8, 64, value_dtype).reduce(cq, n, upload(ctx, data), out_buf)
+        out = download(cq, out_buf, vd.base, (4,) + (vd.shape or (1,)), wait_for=[e])
+        d2 = data.reshape(n, -1)
+        np.testing.assert_equal(out[0].reshape(-1), d2.sum(axis=0))
+        np.testing.assert_equal(out[1].reshape(-1), d2.min(axis=0))
+        np.testing.assert_equal(out[2].reshape(-1), d2.max(axis=0))
+        if prod is not None:
+            np.testing.assert_equal(out[3].reshape(-1), np.full(d2.shape[1], prod, vd.base))
+
+
+def test_generic_accumulator_errors(hip_env):
+    from collision_amd.reduce import ReductionProgram
+    ctx, _ = hip_env
+
+    class Bad(ReductionProgram):
+        accumulator = [("0", "atan2")]
+
+    class TooMany(ReductionProgram):
+        accumulator = [("0", "ADD")] * 5
+
+    for cls in (Bad, TooMany):
+        with pytest.raises(ValueError):
+            cls(ctx, np.dtype("float32"))

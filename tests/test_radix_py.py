@@ -10,7 +10,11 @@ from tests.util import download, upload
 pytestmark = pytest.mark.gpu
 
 VALUE_DTYPES = [np.dtype("uint32"), np.dtype("float64"), np.dtype(("float64", 3)), np.dtype(("float64", 4)),
-                np.dtype(("float32", 3))]
+                np.dtype(("float32", 3)),
+                # widths the scatter passes do not move themselves (sorted as (key, index), gathered once):
+                # the reference specialises for any NumPy dtype (radix.py:16-25)
+                np.dtype("uint8"), np.dtype("int16"), np.dtype(("float64", 8)), np.dtype(("float64", 16)),
+                np.dtype(("float32", 16))]
 
 
 def _sort(ctx, cq, sorter, keys, values=None, value_dtype=None):
@@ -181,7 +185,8 @@ def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
 
 
 @pytest.mark.parametrize("key_dtype,val_bytes", [("uint32", 4), ("uint64", 4), ("uint64", 8), ("uint32", 8), ("uint32", 16),
-                                                 ("uint64", 32), ("uint32", 0), ("uint64", 0)])
+                                                 ("uint64", 32), ("uint32", 0), ("uint64", 0), ("uint32", 1), ("uint64", 2),
+                                                 ("uint32", 64), ("uint64", 128)])
 @pytest.mark.parametrize("n", [(1 << 20) + 12345, (16 << 20) + 12345])
 def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
     """From 1 Mi elements the sort uses the 4096-pair tile, from 16 Mi the 8192-pair one (4-byte
