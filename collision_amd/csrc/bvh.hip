@@ -270,7 +270,7 @@ struct PairSink {
 
 // STATS: count phase-2 steps for col_traverse_stats (diagnostics); the production instance carries
 // no counters.  VEC: record loads as vector loads at a uniform address (ablation).
-template <typename T, bool STATS, bool VEC>
+template <typename T, bool STATS, bool VEC, bool OFF32>
 __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode) {
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     __shared__ uint2 s_buf[TW][CAPW];
     __shared__ u32 s_cnt[TW];
     __shared__ u32 s_base;
-    const u32 lane = lane_id(), w = threadIdx.x / 64;
+    const u32 lane = lane_id();
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));     // scalar: packet, q0, pos stay in SGPRs
     const u32 leaf_start = n - 1;
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
@@ -363,41 +364,87 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             }
         }
 
-        // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain.
-        // (Measured and not kept, round 2: a "pair walk" that fetches both children of a hit node together --
-        // their addresses follow from the parent's links -- and keeps hit children on a lane-indexed stack
-        // halves the chain of dependent loads per packet, but fetches 2 x 38 instead of 63 records: 0.112
-        // instead of 0.077 ms on the uniform 1 M scene, 1.22 instead of 0.86 ms on config 3.  The walk is
-        // bound by the NUMBER of record fetches that miss the scalar cache, not by their latency.)
+        // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain: one
+        // 32-byte record per step at a wave-uniform address (scalar load), tested against the 64 query boxes.
+        //
+        // What bounds it (measured, round 2): the CU's ONE scalar unit, which serves all 32 resident waves.
+        // A step was ~16 scalar instructions (64-bit address arithmetic, load, waits, five s_and over six
+        // compare masks, compares and branches) against 6 vector ones, and every variant that ADDED scalar work
+        // per step lost in proportion, whatever it saved elsewhere:
+        //   * a "pair walk" fetching both children of a hit node together (half the dependent loads per
+        //     packet, 2 x 38 instead of 63 records): 0.112 instead of 0.077 ms (uniform 1 M), 1.22 / 0.86 (config 3);
+        //   * "leaf blocks" (a hit subtree of <= 8..64 leaves tested leaf by leaf from ONE coalesced vector
+        //     load instead of being descended into): 7 more scalar instructions per step to track the subtree
+        //     size: 0.085 instead of 0.069 ms uniform, 0.785 instead of 0.803 ms on config 3.
+        // So the step is written for the scalar unit: a 32-bit record offset (one shift instead of shift + add +
+        // addc; arrays below 4 GB), the six compares narrow EXEC (v_cmpx: lanes that fail drop out, the survivors
+        // are the hits) instead of producing six masks to AND, and runs of misses -- more than half of all steps --
+        // stay inside one asm loop of 8 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
         if (mode & 2) idx = END;
-        auto test = [&](const V4 &a, const V4 &b) -> u64 {
-            // Six lane masks ANDed as scalars: a '&&' chain makes hipcc fetch the record piecemeal behind
-            // branches, and the ballot of a combined bool costs a v_cndmask + v_cmp round trip.
-            return __builtin_amdgcn_ballot_w64(hx > a.x) & __builtin_amdgcn_ballot_w64(lx < b.x) &
-                   __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
-                   __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
-        };
-        while (idx != END) {
-            u32 li = idx;
-            if (VEC) asm volatile("" : "+v"(li));               // vector load at a uniform address
-            const V4 a = rows[2ull * li], b = rows[2ull * li + 1];
-            const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
-            const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
-            const u64 hits = test(a, b);
-            const bool is_leaf = idx >= leaf_start;
-            if (STATS) {
-                trips++; leaf_tests += is_leaf;
-                // how many steps stay within W sorted positions of the block's first leaf (W = 1k, 2k, 4k, 8k)
-                const u32 pos = is_leaf ? idx - leaf_start : idx, b0 = (packet & ~(u32)(TW - 1)) * 64;
-                for (int k = 0; k < 4; k++) win[k] += pos >= b0 && pos < b0 + (1024u << k);
+        if constexpr (sizeof(T) == 4 && OFF32 && !VEC) {
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            const char *rows_b = reinterpret_cast<const char *>(rows);
+            while (idx != END) {
+                u64 hits;
+                u32 off;
+                v8i r;                       // the record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
+                asm volatile("1:\n\t"
+                             "s_lshl_b32 %[off], %[idx], 5\n\t"
+                             "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_cmpx_lt_f32_e32 vcc, s64, %[hx]\n\t"        // lo.x < my hi.x
+                             "v_cmpx_gt_f32_e32 vcc, s68, %[lx]\n\t"        // hi.x > my lo.x
+                             "v_cmpx_lt_f32_e32 vcc, s65, %[hy]\n\t"
+                             "v_cmpx_gt_f32_e32 vcc, s69, %[ly]\n\t"
+                             "v_cmpx_lt_f32_e32 vcc, s66, %[hz]\n\t"
+                             "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
+                             "s_cbranch_execnz 2f\n\t"                     // somebody overlaps: leave the loop
+                             "s_mov_b64 exec, -1\n\t"
+                             "s_mov_b32 %[idx], s67\n\t"                   // nobody: follow the skip link
+                             "s_cmp_lg_u32 s67, -1\n\t"
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b64 %[hits], 0\n\t"
+                             "s_branch 3f\n"
+                             "2:\n\t"
+                             "s_mov_b64 %[hits], exec\n\t"
+                             "s_mov_b64 exec, -1\n"
+                             "3:"
+                             : [idx] "+s"(idx), [hits] "=s"(hits), [off] "=&s"(off), "={s[64:71]}"(r)
+                             : [base] "s"(rows_b), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
+                             : "vcc", "scc", "memory");
+                if (!hits) break;                                           // the chain ended (idx == END)
+                const u32 skip = (u32)r[3], down = (u32)r[7];
+                if (idx >= leaf_start) { sink.emit(hits, qid, down); idx = skip; }
+                else idx = down;
             }
-            u32 next = skip;
-            if (hits) {
-                if (is_leaf) { sink.emit(hits, qid, down); if (STATS) leaf_hits++; }
-                else { next = down; if (STATS) descents++; }
+        } else {
+            auto test = [&](const V4 &a, const V4 &b) -> u64 {
+                return __builtin_amdgcn_ballot_w64(hx > a.x) & __builtin_amdgcn_ballot_w64(lx < b.x) &
+                       __builtin_amdgcn_ballot_w64(hy > a.y) & __builtin_amdgcn_ballot_w64(ly < b.y) &
+                       __builtin_amdgcn_ballot_w64(hz > a.z) & __builtin_amdgcn_ballot_w64(lz < b.z);
+            };
+            while (idx != END) {
+                u32 li = idx;
+                if (VEC) asm volatile("" : "+v"(li));               // vector load at a uniform address
+                const V4 a = rows[2ull * li], b = rows[2ull * li + 1];
+                const u32 skip = (u32) * reinterpret_cast<const Bits *>(&a.w);
+                const u32 down = (u32) * reinterpret_cast<const Bits *>(&b.w);
+                const u64 hits = test(a, b);
+                const bool is_leaf = idx >= leaf_start;
+                if (STATS) {
+                    trips++; leaf_tests += is_leaf;
+                    // how many steps stay within W sorted positions of the block's first leaf (W = 1k, 2k, 4k, 8k)
+                    const u32 p2 = is_leaf ? idx - leaf_start : idx, b0 = (packet & ~(u32)(TW - 1)) * 64;
+                    for (int k = 0; k < 4; k++) win[k] += p2 >= b0 && p2 < b0 + (1024u << k);
+                }
+                u32 next = skip;
+                if (hits) {
+                    if (is_leaf) { sink.emit(hits, qid, down); if (STATS) leaf_hits++; }
+                    else { next = down; if (STATS) descents++; }
+                }
+                idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
-            idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
         }
     }
 
@@ -502,10 +549,13 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     // (variant bit 1): 0.112 ms.
     if (g_traverse_variant & 4) g = dim3(blocks > 256 ? 256 : blocks);
     if (g_traverse_variant & 16) mode |= 8;       // plain packet order
-    if (g_traverse_variant == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
-    else if (st) k_traverse<T, true, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (g_traverse_variant & 2) k_traverse<T, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else k_traverse<T, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
+    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
+    if ((g_traverse_variant & 255) == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
+    else if (st) k_traverse<T, true, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (g_traverse_variant & 2) k_traverse<T, false, true, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32) k_traverse<T, false, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else k_traverse<T, false, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }

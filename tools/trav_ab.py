@@ -26,12 +26,12 @@ for name, coords, radii in scenes:
     cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
     col = Collider(ctx, n, 64, 256)
     col.get_collisions(cq, cb, rb, nb, pb, cap); cq.finish()
-    for variant in (0, 32, 0, 32):      # 0 = pair walk (production), 32 = skip-chain walk (round 1)
+    for label, variant in (("asm walk (production)", 0), ("generic loop", 64), ("asm walk (production)", 0), ("generic loop", 64)):
         cdll().col_debug_traverse(variant)
         def run():
             call.col_fill(cq.stream, nb.ptr, z.ctypes.data, 4, 1)
             call.col_traverse(cq.stream, pb.ptr, nb.ptr, cap, None, col._bounds_buf.ptr, n, 4)
         run(); cq.finish()
         ms = bench.time_events(hip, cq, run, 10)
-        print("%-28s variant %d: %.4f ms, pairs %d" % (name, variant, ms, hip.read_buffer(cq, nb, np.uint32, 1)[0]))
+        print("%-30s %-22s: %.4f ms, pairs %d" % (name, label, ms, hip.read_buffer(cq, nb, np.uint32, 1)[0]))
 cdll().col_debug_traverse(0)
