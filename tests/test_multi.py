@@ -77,11 +77,11 @@ def test_gloo_cpu_world8(tmp_path, partition, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,partition,kind,n", [(2, "morton", "uniform", 60000), (2, "hash", "uniform", 20000),
-                                                    (4, "morton", "clustered", 40000), (5, "morton", "uniform", 50000),
-                                                    (5, "hash", "clustered", 30000)])
+                                                    (4, "morton", "clustered", 40000), (3, "morton", "uniform", 50000),
+                                                    (4, "hash", "clustered", 30000)])
 def test_gloo_gpu_rehearsal(tmp_path, world, partition, kind, n):
     """The real HIP engine on every rank, ranks sharing the one GPU of the test box (at most 6 processes
-    may have it open, and the test runner is one of them: 5 ranks at most).  Besides the global pair set, every rank's sorted codes / ids, node records and boxes
+    may have it open; the test runner and the launcher count: 4 ranks at most).  Besides the global pair set, every rank's sorted codes / ids, node records and boxes
     are compared with the oracle on the spheres that rank owns (dist_worker.per_rank_parity)."""
     res = _run(world, "gpu", partition, n, tmp_path, kind, port=29631 + world + 10 * (partition == "hash"))
     assert res["ok"], res
