@@ -199,13 +199,23 @@ template <typename T> __device__ __forceinline__ Box<T> box_shfl_down(const Box<
 struct __attribute__((packed, aligned(4))) LeafTail { u32 right_edge, id; };
 struct __attribute__((packed, aligned(4))) InnerTail { u32 right_edge, child_a, child_b; };
 
-template <typename T>
+// Diagnostics (col_debug_lbvh: timing ablations of k_chunk) live in a separate instance, DIAG = true, with its
+// own kernel argument; the production instance takes no mode argument and carries none of the branches.
+struct ChunkDiagOff {};
+struct ChunkDiagOn { int mode; };
+template <bool DIAG> struct ChunkDiag { typedef ChunkDiagOff T; };
+template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
+__device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
+__device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
+
+template <typename T, bool DIAG>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial,
-                                             T *__restrict__ tab1, u32 n, int dbg) {
+                                             T *__restrict__ tab1, u32 n, typename ChunkDiag<DIAG>::T diag) {
+    const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     typedef typename BT<T>::V4 V4;
     __shared__ ChunkLds<T> lds;
     __shared__ u32 s_codes[WIN];
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
     row[4] = box.hi[0]; row[5] = box.hi[1]; row[6] = box.hi[2];
 }
 
-int g_dbg = 0;
+int g_dbg = 0;         // process-wide diagnostics switch (col_debug_lbvh); see include/collision_hip.h
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
@@ -412,8 +422,12 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
-    k_chunk<T><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                  (T *)tabs.t[0], n, g_dbg);
+    if (g_dbg)
+        k_chunk<T, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+                                                           (T *)tabs.t[0], n, ChunkDiagOn{g_dbg});
+    else
+        k_chunk<T, false><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+                                                            (T *)tabs.t[0], n, ChunkDiagOff{});
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
     int lin = -1;

@@ -38,7 +38,10 @@ scenes = sorts = 0
 last = time.time()
 while time.time() < t_end:
     # ---- a scene
-    n = int(2 + rng.randint(0, 10) ** 5 * 2 + rng.randint(0, 3000)) if rng.rand() < 0.7 else int(rng.randint(2, 300000))
+    u = rng.rand()
+    # (10 % of the scenes between 1 M and 4.3 M spheres: the 4096-pair tile, both bucket finishes of the MSD plan)
+    n = (int(2 + rng.randint(0, 10) ** 5 * 2 + rng.randint(0, 3000)) if u < 0.65 else int(rng.randint(2, 300000)) if u < 0.9
+         else int(rng.randint(1000000, 4300000)))
     dtype = "float32" if rng.rand() < 0.7 else "float64"
     kind = rng.randint(0, 5)
     if kind == 0:
@@ -60,7 +63,7 @@ while time.time() < t_end:
     coords = pts.astype(dtype)
     scale = (coords.max() - coords.min() + 1e-9) * max(n, 2) ** (-1.0 / 3.0)
     if kind in (1, 2, 3) and n > 20000:                        # dense scenes: keep the pair count checkable
-        scale *= 0.05
+        scale *= 0.05 if n < 1000000 else 0.01
     rk = rng.randint(0, 3)
     radii = (np.full(n, scale * rng.uniform(0.05, 0.6)) if rk == 0 else
              rng.uniform(0.0, scale * 0.8, size=n) if rk == 1 else
@@ -97,7 +100,7 @@ while time.time() < t_end:
     # ---- a sort
     n = int(rng.randint(1, 3000000)) if rng.rand() < 0.5 else int(rng.randint(1, 20000))
     kb = 4 if rng.rand() < 0.7 else 8
-    vb = int(rng.choice([0, 4, 4, 8, 16, 32]))
+    vb = int(rng.choice([0, 4, 4, 8, 16, 32, 1, 2, 64, 128]))
     kd = rng.randint(0, 4)
     keys = (rng.randint(0, 2 ** 32, size=n, dtype=np.uint64) if kd == 0 else
             rng.randint(0, 2 ** rng.randint(1, 31), size=n, dtype=np.uint64) if kd == 1 else
