@@ -145,13 +145,15 @@ class Collider:
 
     def _choose_sort_plan(self):
         """0 = LSD, 1 = MSD (see __init__)."""
-        if self.sort_plan != "auto":
-            return 1 if self.sort_plan == "msd" else 0
+        if self.sort_plan == "lsd":
+            return 0
         if self._plan_word is None:
             word = C.c_void_p()
             call.col_host_alloc(C.byref(word), 64)
             self._plan_word = word.value
             C.c_uint32.from_address(self._plan_word).value = 0
+        if self.sort_plan == "msd":          # pinned: the kernel still reports an oversize bucket (self.oversize_bucket)
+            return 1
         flag = C.c_uint32.from_address(self._plan_word)
         if flag.value:                               # an earlier call met a bucket that did not fit
             flag.value = 0
@@ -165,6 +167,12 @@ class Collider:
             return 0
         self._tried_msd = True
         return 1
+
+    @property
+    def oversize_bucket(self):
+        """Size of a top-digit bucket that did not fit the MSD plan's LDS finish in a call that has completed
+        (0 if none was reported since the word was last cleared).  Read it after the queue has been waited on."""
+        return C.c_uint32.from_address(self._plan_word).value if self._plan_word else 0
 
     def __del__(self):
         word, self._plan_word = getattr(self, "_plan_word", None), None

@@ -279,3 +279,35 @@ def test_auto_plan_falls_back_after_an_oversize_bucket(oracle, hip_env):
         np.testing.assert_array_equal(st["codes"], ref["codes"])
         np.testing.assert_array_equal(st["ids"], ref["ids"])
     assert collider._lsd_calls_left > 0                        # it has switched
+
+
+def test_back_to_back_calls_on_a_clustered_scene(oracle, hip_env):
+    """Calls enqueued WITHOUT waiting in between take the plan chosen when they were made: until the oversize
+    word of an earlier call has been written that is the MSD plan through its slow path -- still exact -- and
+    a call made after the word is visible (at the latest after a wait) switches to the LSD plan.  A pinned MSD
+    plan reports the oversize bucket too."""
+    from collision_amd import hip
+    from tests.util import upload
+    ctx, cq = hip_env
+    n = 150000
+    coords, radii = clustered_scene(n, 0.003, 0.0003, "float32")
+    collider = Collider(ctx, n, 8, 64, np.dtype("float32"))
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=1 << 24)
+    cb, rb = upload(ctx, pad4(coords)), upload(ctx, radii)
+    outs = [(hip.Buffer(ctx, 4), hip.Buffer(ctx, ref["count"] * 8)) for _ in range(6)]
+    for nb, pb in outs:                                        # six calls, no synchronisation
+        collider.get_collisions(cq, cb, rb, nb, pb, ref["count"])
+    cq.finish()
+    for nb, pb in outs:
+        assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == ref["count"]
+        assert pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2))) == pair_set(ref["pairs"])
+    assert collider.oversize_bucket > 8192 or collider._lsd_calls_left > 0      # reported, or already acted upon
+    collider.get_collisions(cq, cb, rb, outs[0][0], outs[0][1], ref["count"])     # sees the word: LSD from here on
+    assert collider._lsd_calls_left > 0
+    cq.finish()
+    pinned = Collider(ctx, n, 8, 64, np.dtype("float32"))
+    pinned.sort_plan = "msd"
+    pinned.get_collisions(cq, cb, rb, outs[1][0], outs[1][1], ref["count"])
+    cq.finish()
+    assert pinned.oversize_bucket > 8192
+    assert int(hip.read_buffer(cq, outs[1][0], np.uint32, 1)[0]) == ref["count"]
