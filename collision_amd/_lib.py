@@ -80,32 +80,23 @@ _PROTOS = {
     "col_collide": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_uint32]),
-    "col_pack_spheres": (None, [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]),
-    "col_pack5": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_unpack5": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
-                                        C.c_uint32, C.c_void_p, C.c_void_p]),
-    "col_pack5_lists": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
-                               C.c_uint32, C.c_void_p, C.c_uint32]),
+    "col_sample_rows": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
+    "col_fold_boxes_strided": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
+    "col_splitters_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_bucketize_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_select_overlap": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "col_traverse_ghost": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_digit_counts": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "col_pack_records": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
+    "col_unpack_records": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
+    "col_region_box": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_pack_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
+                              C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
-    "col_fold_boxes": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_fold_boxes_strided": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_sample_rows": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_region_box": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "col_pack5_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
-                               C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
-    "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_sample_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_splitters_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_digit_counts": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_expand_counts": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_radix": (C.c_int, [C.c_int]),

@@ -10,7 +10,7 @@ New work -- the reference is single-device.  Spheres arri
    quantiles of the sample codes (balanced for clustered scenes too), one radix pass that groups the
    spheres by owner rank, a count all-gather (the step's ONE host sync -- the local pipeline needs the
    number of owned spheres on the host; the grouping scatter and the packing run meanwhile) and one
-   variable-size all-to-all of 5-word records ``(x, y, z, r, id)``.  Each rank now owns a contiguous
+   variable-size all-to-all of transport records ``(x, y, z, r, id)`` (5 words for f32 coordinates, 9 for f64).  Each rank now owns a contiguous
    Morton range, i.e. a compact region.  With ``partition="hash"`` this step is skipped and every rank
    keeps its hash subset (its region is then the whole scene).
 3. Two branches run concurrently from here:
@@ -45,7 +45,7 @@ from . import hip
 from ._lib import call
 from .misc import roundUp
 
-SAMPLES = 1024          # splitter samples per rank
+SAMPLES = 1022          # splitter samples per rank (+ 2 range rows = 1024 rows per rank; 16 ranks fill k_splitters' LDS)
 MAX_PEERS = 8           # halo peers per rank (col_select_overlap_multi): world sizes up to 16
 
 
@@ -163,8 +163,8 @@ class ProtocolOps:
         torch = self.torch
         if n == 0:
             inf = float("inf")
-            body = torch.tensor([inf, inf, inf, 0.0], dtype=torch.float32, device=rows.device).repeat(SAMPLES, 1)
-            tail = torch.tensor([[inf] * 4, [-inf] * 4], dtype=torch.float32, device=rows.device)
+            body = torch.tensor([inf, inf, inf, 0.0], dtype=rows.dtype, device=rows.device).repeat(SAMPLES, 1)
+            tail = torch.tensor([[inf] * 4, [-inf] * 4], dtype=rows.dtype, device=rows.device)
             return torch.cat([body, tail])
         pos = (torch.arange(SAMPLES, device=rows.device, dtype=torch.int64) * (n - 1)) // (SAMPLES - 1)
         return torch.cat([rows[pos], rows[:n].min(dim=0).values[None], rows[:n].max(dim=0).values[None]]).contiguous()
@@ -187,7 +187,7 @@ class ProtocolOps:
         torch = self.torch
         if n == 0:
             inf = float("inf")
-            return torch.tensor([inf] * 4 + [-inf] * 4, dtype=torch.float32, device=rows.device)
+            return torch.tensor([inf] * 4 + [-inf] * 4, dtype=rows.dtype, device=rows.device)
         mn, mx = rows[:n].min(dim=0).values, rows[:n].max(dim=0).values
         out = torch.cat([mn - mx[3], mx + mx[3]])
         out[3] = 0
@@ -198,11 +198,16 @@ class ProtocolOps:
 class HipEngine(ProtocolOps):
     """Device work of one rank through the C ABI, on torch CUDA tensors (torch = memory + streams)."""
 
-    def __init__(self, ctx, capacity, group_size, pair_capacity):
+    def __init__(self, ctx, capacity, group_size, pair_capacity, coord_dtype=np.dtype("float32")):
         import torch
         from .collision import Collider
         self.torch = torch
         self.ctx = ctx
+        self.coord_dtype = np.dtype(coord_dtype)
+        if self.coord_dtype not in (np.dtype("float32"), np.dtype("float64")):
+            raise ValueError("Unsupported coordinate dtype on the multi-GPU path: {}".format(coord_dtype))
+        self.cb = self.coord_dtype.itemsize                   # coord_bytes of every C call below
+        self.rw = 4 * self.cb // 4 + 1                        # words per transport record: (x, y, z, r) + gid
         self.device = torch.device("cuda", ctx.device)
         torch.cuda.set_device(self.device)
         self.main = torch.cuda.current_stream()
@@ -211,8 +216,9 @@ class HipEngine(ProtocolOps):
         self.cq_side = hip.CommandQueue(ctx, stream=self.side.cuda_stream)
         self.capacity, self.pair_capacity = capacity, pair_capacity
         self.group_size = group_size
-        f32, i32 = torch.float32, torch.int32
+        f32, i32 = (torch.float32 if self.cb == 4 else torch.float64), torch.int32
         dev = self.device
+        self._f = f32
 
         def rows(n):
             return torch.zeros((n, 4), dtype=f32, device=dev)
@@ -221,7 +227,7 @@ class HipEngine(ProtocolOps):
             return torch.zeros(n, dtype=i32, device=dev)
 
         def recs(n):
-            return torch.zeros((n, 5), dtype=i32, device=dev)       # transport records (x, y, z, r, gid)
+            return torch.zeros((n, self.rw), dtype=i32, device=dev)       # transport records (x, y, z, r, gid)
 
         self._recs = recs
         self.rows_in, self.gids_in = rows(capacity), ints(capacity)
@@ -244,10 +250,11 @@ class HipEngine(ProtocolOps):
         self.box8 = torch.zeros(8, dtype=f32, device=dev)
         self.sample_codes = ints(16 * (SAMPLES + 2))
         self.split, self.owner_counts = ints(256), ints(256)
-        self.collider = Collider(ctx, capacity, 64, group_size)
+        self.collider = Collider(ctx, capacity, 64, group_size, self.coord_dtype)
         self.collider._allocate()
-        self._reduce_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(0, 4))
-        self._reduce_scratch_side = hip.Buffer(ctx, call.col_reduce_scratch_bytes(0, 4))
+        self._tc = 0 if self.cb == 4 else 1                   # COL_F32 / COL_F64
+        self._reduce_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(self._tc, 4))
+        self._reduce_scratch_side = hip.Buffer(ctx, call.col_reduce_scratch_bytes(self._tc, 4))
         self.n_owned = 0
         self._nb = 0
 
@@ -257,7 +264,7 @@ class HipEngine(ProtocolOps):
         n = len(coords4)
         if n > self.capacity:
             raise ValueError("rank capacity %d < %d local spheres" % (self.capacity, n))
-        host = np.array(coords4, dtype=np.float32, copy=True)
+        host = np.array(coords4, dtype=self.coord_dtype, copy=True)
         host[:, 3] = radii
         self.rows_in[:n] = torch.from_numpy(host).to(self.device)
         self.gids_in[:n] = torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32)).to(self.device)
@@ -280,18 +287,19 @@ class HipEngine(ProtocolOps):
     # -- steps (all asynchronous, on the main stream unless they belong to the halo branch)
     def sample_and_range(self, rows, n):
         s = self.cq.stream
-        call.col_sample_rows(s, rows.data_ptr(), n, SAMPLES, self.payload.data_ptr())
+        call.col_sample_rows(s, rows.data_ptr(), n, SAMPLES, self.payload.data_ptr(), self.cb)
         if n == 0:
             self.payload[SAMPLES] = float("inf")
             self.payload[SAMPLES + 1] = float("-inf")
         else:
-            call.col_reduce(s, rows.data_ptr(), n, 0, 4, 0, self._reduce_scratch.ptr, self.payload.data_ptr() + 16 * SAMPLES)
+            call.col_reduce(s, rows.data_ptr(), n, self._tc, 4, 0, self._reduce_scratch.ptr,
+                            self.payload.data_ptr() + 4 * self.cb * SAMPLES)
         return self.payload
 
     def fold_ranges(self, gathered):
         world = int(gathered.shape[0])
-        call.col_fold_boxes_strided(self.cq.stream, gathered.data_ptr() + 16 * SAMPLES, world, 4 * (SAMPLES + 2),
-                                    self.grange8.data_ptr())
+        call.col_fold_boxes_strided(self.cq.stream, gathered.data_ptr() + 4 * self.cb * SAMPLES, world, 4 * (SAMPLES + 2),
+                                    self.grange8.data_ptr(), self.cb)
         return self.grange8
 
     def codes_of_rows(self, rows, range8):
@@ -299,7 +307,7 @@ class HipEngine(ProtocolOps):
         m = int(rows.shape[0])
         if m > self.sample_codes.numel():
             raise ValueError("more than %d sample rows" % self.sample_codes.numel())
-        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), m, m, 4, self.sample_codes.data_ptr(), None)
+        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), m, m, self.cb, self.sample_codes.data_ptr(), None)
         return self.sample_codes[:m]
 
     def splitters_from(self, gathered, grange, world):
@@ -309,7 +317,7 @@ class HipEngine(ProtocolOps):
 
     def codes_of(self, rows, n, range8):
         """Morton codes of the local rows under the global scene range (unsorted) + the index ramp."""
-        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), n, n, 4, self.codes.data_ptr(),
+        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), n, n, self.cb, self.codes.data_ptr(),
                         self.iota.data_ptr())
         return self.codes
 
@@ -338,13 +346,13 @@ class HipEngine(ProtocolOps):
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         """out5[out_offset + i] = (rows[idx[idx_offset + i]], gids[...]) for i < n (idx None = identity)."""
-        call.col_pack5(self.cq.stream, rows.data_ptr(), gids.data_ptr(),
-                       None if idx is None else idx.data_ptr() + 4 * idx_offset, n,
-                       out5.data_ptr() + 20 * out_offset)
+        call.col_pack_records(self.cq.stream, rows.data_ptr(), gids.data_ptr(),
+                              None if idx is None else idx.data_ptr() + 4 * idx_offset, n,
+                              out5.data_ptr() + 4 * self.rw * out_offset, self.cb)
 
     def unpack5(self, rec5, n, rows, gids, radii=None):
-        call.col_unpack5(self.cq.stream, rec5.data_ptr(), n, rows.data_ptr(), gids.data_ptr(),
-                         None if radii is None else radii.data_ptr())
+        call.col_unpack_records(self.cq.stream, rec5.data_ptr(), n, rows.data_ptr(), gids.data_ptr(),
+                                None if radii is None else radii.data_ptr(), self.cb)
 
     def collide(self, rows, gids, n):
         """Single-GPU path on the owned spheres (main stream); pairs come out as global ids."""
@@ -355,8 +363,8 @@ class HipEngine(ProtocolOps):
             return                                # (col_collide zeroes the counter itself)
         c = self.collider
         if rows is not self.owned_rows:           # owned rows come out of unpack5 with radii already split off
-            call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr())
-        call.col_collide_plan(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), 4,
+            call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr(), self.cb)
+        call.col_collide_plan(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), self.cb,
                               c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
                               c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
                               self.counter.data_ptr(), self.pairs.data_ptr(), self.pair_capacity,
@@ -371,8 +379,8 @@ class HipEngine(ProtocolOps):
             self.box8[:4] = float("inf")
             self.box8[4:] = float("-inf")
         else:
-            call.col_reduce(s, rows.data_ptr(), n, 0, 4, 0, self._reduce_scratch_side.ptr, self.minmax8.data_ptr())
-            call.col_region_box(s, self.minmax8.data_ptr(), self.box8.data_ptr())
+            call.col_reduce(s, rows.data_ptr(), n, self._tc, 4, 0, self._reduce_scratch_side.ptr, self.minmax8.data_ptr())
+            call.col_region_box(s, self.minmax8.data_ptr(), self.box8.data_ptr(), self.cb)
         return self.box8
 
     def ensure_slots(self, slot, n_out, n_in):
@@ -392,10 +400,10 @@ class HipEngine(ProtocolOps):
             return
         arr = (C.c_int * len(peers))(*peers)
         call.col_select_overlap_multi(s, rows.data_ptr(), n, boxes_dev.data_ptr(), arr, len(peers),
-                                      self.capacity, self.sel_lists.data_ptr(), self.sel_counts.data_ptr())
-        call.col_pack5_slots(s, rows.data_ptr(), gids.data_ptr(), self.sel_lists.data_ptr(), self.capacity,
-                             self.sel_counts.data_ptr(), len(peers), min(max(n, 1), slot), self.halo_send.data_ptr(),
-                             int(self.halo_send.shape[0]), slot)
+                                      self.capacity, self.sel_lists.data_ptr(), self.sel_counts.data_ptr(), self.cb)
+        call.col_pack_slots(s, rows.data_ptr(), gids.data_ptr(), self.sel_lists.data_ptr(), self.capacity,
+                            self.sel_counts.data_ptr(), len(peers), min(max(n, 1), slot), self.halo_send.data_ptr(),
+                            int(self.halo_send.shape[0]), slot, self.cb)
 
     def ghost_queries(self, n_in, slot, owned_gids):
         if self.n_owned == 0 or n_in == 0:
@@ -403,7 +411,7 @@ class HipEngine(ProtocolOps):
         call.col_traverse_ghost_slots(self.cq.stream, self.halo_recv.data_ptr(), n_in, slot,
                                       self.collider._bounds_buf.ptr, self.n_owned, owned_gids.data_ptr(),
                                       self.pairs.data_ptr(), self.counter.data_ptr(), self.pair_capacity,
-                                      self.flags.data_ptr())
+                                      self.flags.data_ptr(), self.cb)
 
     # -- results (these synchronise)
     def halo_stats(self):
@@ -427,13 +435,13 @@ class HipEngine(ProtocolOps):
 # --------------------------------------------------------------------------- the protocol
 class DistributedCollider:
     def __init__(self, ctx, dist, n_local, group_size=256, pair_capacity=1 << 19, partition="morton",
-                 slack=1.6, engine=None, exercise_single_rank=False, halo_slot=None):
+                 slack=1.6, engine=None, exercise_single_rank=False, halo_slot=None, coord_dtype=np.dtype("float32")):
         if partition not in ("morton", "hash"):
             raise ValueError("partition must be 'morton' or 'hash'")
         self.dist, self.partition = dist, partition
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         capacity = roundUp(int(n_local * slack) + 4096, 2 * group_size)
-        self.engine = engine or HipEngine(ctx, capacity, group_size, pair_capacity)
+        self.engine = engine or HipEngine(ctx, capacity, group_size, pair_capacity, coord_dtype)
         self.capacity = capacity
         self.x = Exchange(dist, self.engine.device)
         self.cq = getattr(self.engine, "cq", None)

@@ -232,68 +232,51 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
 /* ---------------------------------------------------------------- multi-GPU helpers
  * New work (the reference is single-device): device side of the sphere
  * repartition / halo exchange / ghost queries driven by collision_amd/multi.py over RCCL.
- * f32 coordinates only.  Packed rows are (x, y, z, r). */
-int col_pack_spheres(void *stream, const void *coords, const void *radii, const uint32_t *gids,
-                     const uint32_t *idx, uint32_t n, void *rows, uint32_t *out_gids);
-int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii);
+ * coord_bytes 4 | 8.  Rows are 4 scalars (x, y, z, r); a transport record is those 4 scalars
+ * followed by the 32-bit global id: 5 words (f32) or 9 words (f64). */
+/* out_rows[i] = rows[i * (n - 1) / (samples - 1)]: a rank's contribution to the splitter sample (n == 0: rows at +inf) */
+int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows, int coord_bytes);
+/* out8 = [min of the min rows, max of the max rows] of `count` gathered boxes, `stride_scalars` apart
+ * (the tail of each rank's block of the first all-gather) */
+int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_scalars, void *out8,
+                           int coord_bytes);
+/* world - 1 quantiles of `count` <= 16384 gathered sample codes (sorted on the device) */
+int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out);
 /* dest[i] = number of (sorted, device) splitters <= codes[i]: the owner rank of a Morton code */
 int col_bucketize_u32(void *stream, const uint32_t *codes, uint32_t n, const uint32_t *splitters,
                       uint32_t n_split, uint32_t *dest);
-/* 5-word transport records (x, y, z, r, gid): one all-to-all moves a sphere */
-int col_pack5(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec);
-int col_unpack5(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii);
+/* elements per digit from the scanned digit-major histogram of a radix pass over the owner index */
+int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
+                     uint32_t *out);
+/* transport records: rec[i] = (rows[idx[i]], gids[idx[i]]) (idx NULL = identity) and back */
+int col_pack_records(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec,
+                     int coord_bytes);
+int col_unpack_records(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii,
+                       int coord_bytes);
+int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii, int coord_bytes);
+/* [min row, max row] of (x, y, z, r) rows (col_reduce, MINMAX, width 4) -> box (min centre - max r, max centre + max r) */
+int col_region_box(void *stream, const void *minmax8, void *out8, int coord_bytes);
 /* halo selection in one launch: boxes = DEVICE array [world][8] (lo.xyz,-,hi.xyz,-) as produced by
  * the AABB all-gather; peers = HOST array of n_peers <= 8 rank numbers; lists[k*stride ...] and
  * counts[k] (zeroed by the caller) receive the spheres overlapping boxes[peers[k]] */
 int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
-                             int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts);
-/* pack the n_lists lists back to back into transport records; sizes are read on the device */
-int col_pack5_lists(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists,
-                    uint32_t stride, const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec,
-                    uint32_t rec_capacity);
-/* col_pack5_lists into fixed SLOTS of 1 + slot_records records: a header record (first word = the list's full
- * length) followed by min(length, slot_records) records; slot_records == 0 is col_pack5_lists.  A fixed-size
+                             int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes);
+/* the n_lists lists as fixed SLOTS of 1 + slot_records records each: a header record (first word = the list's
+ * full length) followed by min(length, slot_records) records; list sizes are read on the device.  A fixed-size
  * exchange of such slots needs no count exchange and no host sync; the receiver learns the lengths -- and an
  * overflow -- from the headers. */
-int col_pack5_slots(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
-                    const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity,
-                    uint32_t slot_records);
-/* col_traverse_ghost over n_slots received slots; flags[0] = max(flags[0], longest header length),
- * flags[1] += ghosts queried (2 x uint32, zeroed by the caller) */
+int col_pack_slots(void *stream, const void *rows, const uint32_t *gids, const uint32_t *lists, uint32_t stride,
+                   const uint32_t *counts, int n_lists, uint32_t max_per_list, void *rec, uint32_t rec_capacity,
+                   uint32_t slot_records, int coord_bytes);
+/* ghost spheres (n_slots received slots) as queries against the local tree (bounds with links); emits
+ * (ghost gid, local_gids[hit]); counter is NOT reset (it continues the local pair list);
+ * flags[0] = max(flags[0], longest header length), flags[1] += ghosts queried (2 x uint32, zeroed by the caller) */
 int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
                              uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter,
-                             uint32_t capacity, uint32_t *flags);
-/* indices of rows whose box strictly overlaps aabb (2 x vec4) appended to out; *count zeroed by caller */
-int col_select_overlap(void *stream, const void *rows, uint32_t n, const void *aabb, uint32_t *out,
-                       uint32_t *count);
-/* ghost spheres as queries against the local tree (bounds with links); emits
- * (ghost gid, local_gids[hit]); counter is NOT reset (it continues the local pair list) */
-int col_traverse_ghost(void *stream, const void *ghost_rows, const uint32_t *ghost_gids,
-                       uint32_t n_ghost, const void *bounds, uint32_t n, const uint32_t *local_gids,
-                       uint32_t *pairs, uint32_t *counter, uint32_t capacity);
+                             uint32_t capacity, uint32_t *flags, int coord_bytes);
 /* pairs[first .. min(*count, capacity)) : index -> gids[index] */
 int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first,
                         uint32_t capacity, const uint32_t *gids);
-
-/* Small steps of the multi-GPU protocol (collision_amd/multi.py), one launch each:
- *   col_fold_boxes     out8 = [min of the min rows, max of the max rows] of `count` gathered boxes
- *   col_sample_u32     out[i] = codes[i * (n - 1) / (samples - 1)]  (n == 0: 1 << 30)
- *   col_splitters_u32  world - 1 quantiles of `count` <= 8192 gathered samples (sorted on the device)
- *   col_digit_counts   elements per digit from the scanned digit-major histogram of a radix pass
- *   col_expand_counts  out[peers[k]] = counts[k], 0 for the other ranks                        */
-int col_fold_boxes(void *stream, const void *boxes, uint32_t count, void *out8);
-/* the same with the boxes `stride_floats` apart (the tail of each rank's block of a larger all-gather) */
-int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_floats, void *out8);
-/* out_rows[i] = rows[i * (n - 1) / (samples - 1)]: a rank's contribution to the splitter sample (n == 0: rows at +inf) */
-int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows);
-/* [min row, max row] of (x, y, z, r) rows (col_reduce, MINMAX, width 4) -> box (min centre - max r, max centre + max r) */
-int col_region_box(void *stream, const void *minmax8, void *out8);
-int col_sample_u32(void *stream, const uint32_t *codes, uint32_t n, uint32_t samples, uint32_t *out);
-int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out);
-int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
-                     uint32_t *out);
-int col_expand_counts(void *stream, const uint32_t *counts, const int *peers, int n_peers, uint32_t world,
-                      uint32_t *out);
 
 /* ---------------------------------------------------------------- index / offset
  * collision/index.cl:1-13 (Indexer.gather/scatter, index.py:23-55) and

@@ -27,20 +27,23 @@ class OracleEngine(_protocol_ops()):
     """CPU stand-in for collision_amd.multi.HipEngine (same methods, torch CPU tensors); the small
     tensor steps between the collectives are ProtocolOps' tensor-library versions."""
 
-    def __init__(self, capacity, pair_capacity):
+    def __init__(self, capacity, pair_capacity, coord_dtype=np.dtype("float32")):
         import contextlib
         import torch
         import oracle
         self.torch, self.oracle, self._null = torch, oracle, contextlib.nullcontext
         self.device = torch.device("cpu")
         self.capacity, self.pair_capacity = capacity, pair_capacity
-        z4 = lambda n: torch.zeros((n, 4), dtype=torch.float32)
+        self.coord_dtype = np.dtype(coord_dtype)
+        self._f = torch.float32 if self.coord_dtype.itemsize == 4 else torch.float64
+        self._wf = self.coord_dtype.itemsize // 4                      # int32 words per scalar
+        z4 = lambda n: torch.zeros((n, 4), dtype=self._f)
         zi = lambda n: torch.zeros(n, dtype=torch.int32)
-        self._z5 = lambda n: torch.zeros((n, 5), dtype=torch.int32)
+        self._z5 = lambda n: torch.zeros((n, 4 * self._wf + 1), dtype=torch.int32)
         self.rows_in, self.gids_in = z4(capacity), zi(capacity)
         self.send5, self.recv5 = self._z5(capacity), self._z5(capacity)
         self.owned_rows, self.owned_gids = z4(capacity), zi(capacity)
-        self.radii = torch.zeros(capacity)
+        self.radii = torch.zeros(capacity, dtype=self._f)
         self.halo_send = self.halo_recv = None
         self.perm = zi(capacity)
         self.found = []
@@ -49,7 +52,7 @@ class OracleEngine(_protocol_ops()):
 
     def load(self, coords4, radii, gids):
         n = len(coords4)
-        host = np.array(coords4, dtype=np.float32, copy=True)
+        host = np.array(coords4, dtype=self.coord_dtype, copy=True)
         host[:, 3] = radii
         self.rows_in[:n] = self.torch.from_numpy(host)
         self.gids_in[:n] = self.torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32))
@@ -90,13 +93,13 @@ class OracleEngine(_protocol_ops()):
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         t = self.torch
         sel = slice(0, n) if idx is None else idx[idx_offset:idx_offset + n].long()
-        out5[out_offset:out_offset + n, :4] = rows[sel].view(t.int32)
-        out5[out_offset:out_offset + n, 4] = gids[sel]
+        out5[out_offset:out_offset + n, :4 * self._wf] = rows[sel].contiguous().view(t.int32)
+        out5[out_offset:out_offset + n, 4 * self._wf] = gids[sel]
 
     def unpack5(self, rec5, n, rows, gids, radii=None):
         t = self.torch
-        rows[:n] = rec5[:n, :4].contiguous().view(t.float32)
-        gids[:n] = rec5[:n, 4]
+        rows[:n] = rec5[:n, :4 * self._wf].contiguous().view(self._f)
+        gids[:n] = rec5[:n, 4 * self._wf]
 
     def collide(self, rows, gids, n):
         self.n_owned, self.found = n, []
@@ -109,8 +112,8 @@ class OracleEngine(_protocol_ops()):
             count = self.oracle.collide(c4, radii, capacity=0, want=False)["count"]
             res = self.oracle.collide(c4, radii, capacity=count, want=False)
             self.found = [(int(self._gids[a]), int(self._gids[b])) for a, b in res["pairs"]]
-        self._lo = (self._rows[:, :3] - radii[:, None]).astype(np.float32)
-        self._hi = (self._rows[:, :3] + radii[:, None]).astype(np.float32)
+        self._lo = (self._rows[:, :3] - radii[:, None]).astype(self.coord_dtype)
+        self._hi = (self._rows[:, :3] + radii[:, None]).astype(self.coord_dtype)
 
     def ensure_slots(self, slot, n_out, n_in):
         want_s, want_r = max(1, n_out) * (slot + 1), max(1, n_in) * (slot + 1)
@@ -143,10 +146,10 @@ class OracleEngine(_protocol_ops()):
             if self.n_owned == 0 or cnt == 0:
                 continue
             rec = self.halo_recv[base + 1:base + 1 + cnt]
-            g = rec[:, :4].contiguous().view(self.torch.float32).numpy()
-            glo = (g[:, :3] - g[:, 3:4]).astype(np.float32)
-            ghi = (g[:, :3] + g[:, 3:4]).astype(np.float32)
-            gg = rec[:, 4].numpy().view(np.uint32)
+            g = rec[:, :4 * self._wf].contiguous().view(self._f).numpy()
+            glo = (g[:, :3] - g[:, 3:4]).astype(self.coord_dtype)
+            ghi = (g[:, :3] + g[:, 3:4]).astype(self.coord_dtype)
+            gg = rec[:, 4 * self._wf].contiguous().numpy().view(np.uint32)
             self._ghosts += cnt
             for i in range(cnt):
                 hit = ((ghi[i] > self._lo) & (glo[i] < self._hi)).all(axis=1)
@@ -198,7 +201,7 @@ def per_rank_parity(dc):
     codes = hip_read(cq, c._codes_bufs[1], np.uint32, padded)
     ids = hip_read(cq, c._ids_bufs[1], np.uint32, padded)
     nodes = hip_read(cq, c._nodes_buf, Node, 2 * m - 1)
-    bounds = hip_read(cq, c._bounds_buf, np.float32, (2 * m - 1, 2, 4))
+    bounds = hip_read(cq, c._bounds_buf, e.coord_dtype, (2 * m - 1, 2, 4))
     leaf = m - 1
     checks = (("codes", codes, ref["codes"]), ("ids", ids, ref["ids"]),
               ("right_edge", nodes["right_edge"], ref["nodes"]["right_edge"]),
@@ -221,6 +224,7 @@ def main():
     mode, partition, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
     halo_slot = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
+    coord_dtype = np.dtype(sys.argv[7]) if len(sys.argv) > 7 else np.dtype("float32")
     import torch  # noqa: F401
     import torch.distributed as dist
     dist.init_process_group("gloo")
@@ -229,6 +233,7 @@ def main():
     from collision_amd.multi import DistributedCollider, hash_owner
 
     coords, radii = scene(n, world, kind)
+    coords, radii = coords.astype(coord_dtype), radii.astype(coord_dtype)
     gids = np.arange(n, dtype=np.uint32)
     mine = hash_owner(gids, world) == rank
     ctx = hip.Context(0)
@@ -236,9 +241,9 @@ def main():
     if mode == "cpu":
         from collision_amd.misc import roundUp
         cap = roundUp(int(int(mine.sum()) * 3.0) + 4096, 2 * 64)     # as DistributedCollider sizes it (slack 3)
-        engine = OracleEngine(cap, 1 << 20)
+        engine = OracleEngine(cap, 1 << 20, coord_dtype)
     dc = DistributedCollider(ctx, dist, int(mine.sum()), group_size=64, pair_capacity=1 << 22, partition=partition,
-                             slack=3.0, engine=engine, halo_slot=halo_slot)
+                             slack=3.0, engine=engine, halo_slot=halo_slot, coord_dtype=coord_dtype)
     dc.set_local_spheres(coords[mine], radii[mine], gids[mine])
     for _ in range(2):                       # twice: buffers are reused across steps
         dc.step()

@@ -36,12 +36,12 @@ def test_hash_owner_is_balanced():
     assert counts.min() > 0.9 * (1 << 13) and counts.max() < 1.1 * (1 << 13)
 
 
-def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0):
+def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32"):
     out = tmp_path / ("result_%s_%s_%d.json" % (mode, partition, world))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"),
-           mode, partition, str(n), str(out), kind, str(halo_slot)]
+           mode, partition, str(n), str(out), kind, str(halo_slot), dtype]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     return json.loads(out.read_text())
@@ -53,6 +53,12 @@ def test_gloo_cpu_world(tmp_path, world, partition, kind):
     res = _run(world, "cpu", partition, 1500, tmp_path, kind, port=29611 + world)
     assert res["ok"], res
     assert res["expected"] > 100
+
+
+def test_gloo_cpu_world_float64(tmp_path):
+    """f64 coordinates on the multi-rank path: 9-word transport records."""
+    res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29648, dtype="float64")
+    assert res["ok"], res
 
 
 def test_halo_slot_overflow_is_repaired(tmp_path):
@@ -88,6 +94,16 @@ def test_gloo_gpu_rehearsal(tmp_path, world, partition, kind, n):
     assert all(s["rank_parity"] == "ok" for s in res["stats"])
     if partition == "morton" and kind == "uniform" and world == 2:      # a spatial partition keeps the halo thin
         assert max(s["ghosts"] for s in res["stats"]) < 0.6 * n / world
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["morton", "hash"])
+def test_gloo_gpu_rehearsal_float64(tmp_path, partition):
+    """f64 coordinates through the real HIP engine (9-word transport records, f64 tree and ghost walk), with the
+    per-rank parity check against the f64 oracle."""
+    res = _run(3, "gpu", partition, 30000, tmp_path, "uniform", port=29649 + (partition == "hash"), dtype="float64")
+    assert res["ok"], res
+    assert all(s["rank_parity"] == "ok" for s in res["stats"])
 
 
 @pytest.mark.gpu
