@@ -268,6 +268,40 @@ struct PairSink {
     }
 };
 
+// min (MAX = false) or max of v over the 64 lanes, as a wave-uniform value.  DPP steps: xor 1, xor 2 (quad_perm),
+// row_half_mirror, row_mirror (now every lane holds its row's result), row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3: lane 63 holds the result.  A lane a step does not reach gets its own value
+// back (`old` = v), which min / max ignore.  Only the conservative screening box is built from it: v_min / v_max
+// semantics for NaNs are fine there.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(u32)b, hi = (int)(u32)((u64)b >> 32);
+    const u32 l2 = (u32)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const u32 h2 = (u32)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((u64)h2 << 32) | l2));
+}
+template <typename T, bool MAX> __device__ __forceinline__ T wave_min_max(T v) {
+    auto op = [](T a, T b) -> T {
+        if constexpr (sizeof(T) == 4) return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b);
+        else return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b);
+    };
+    v = op(v, dpp_f<0xB1, 0xF>(v));          // quad_perm [1, 0, 3, 2]
+    v = op(v, dpp_f<0x4E, 0xF>(v));          // quad_perm [2, 3, 0, 1]
+    v = op(v, dpp_f<0x141, 0xF>(v));         // row_half_mirror
+    v = op(v, dpp_f<0x140, 0xF>(v));         // row_mirror
+    v = op(v, dpp_f<0x142, 0xA>(v));         // row_bcast15 -> rows 1, 3
+    v = op(v, dpp_f<0x143, 0xC>(v));         // row_bcast31 -> rows 2, 3
+    if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    else {
+        const long long b = __double_as_longlong(v);
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)b >> 32), 63);
+        return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+    }
+}
+
 // STATS: count phase-2 steps for col_traverse_stats (diagnostics); the production instance carries
 // no counters.  VEC: record loads as vector loads at a uniform address (ablation).
 template <typename T, bool STATS, bool VEC, bool OFF32>
@@ -316,15 +350,35 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         // always survives).  The three axes sit in 10-bit fields of one word, and "a >= b in every
         // field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
         if (!(mode & 1)) {
-            T ul[3] = {lx, ly, lz}, uh[3] = {hx, hy, hz};
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            // the packet's union box: six wave reductions on the DPP network (6 steps + one v_readlane each,
+            // no LDS) instead of six xor-shuffle butterflies through ds_bpermute (36 LDS round trips)
+            T ul[3], uh[3];
+            if constexpr (sizeof(T) == 4) {
+                // (f32: the six reductions interleaved in one asm block, one v_min/v_max_f32_dpp per step -- the
+                // dependent steps of one reduction are six instructions apart, which covers the two wait states a
+                // DPP read needs after a VALU write; hipcc spends five instructions per step on the same thing)
+                float a0 = lx, a1 = ly, a2 = lz, b0 = hx, b1 = hy, b2 = hz;
+#define COL_DPP_STEP(ctrl)                                                      \
+                "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t" \
+                "v_max_f32_dpp %3, %3, %3 " ctrl "\n\tv_max_f32_dpp %4, %4, %4 " ctrl "\n\tv_max_f32_dpp %5, %5, %5 " ctrl "\n\t"
+                asm volatile(COL_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                             COL_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                             COL_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                             COL_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                             COL_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                             COL_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                             "s_nop 1"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
+#undef COL_DPP_STEP
+                const float red[6] = {a0, a1, a2, b0, b1, b2};
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    const T l2 = __shfl_xor(ul[a], o, COL_WAVE), h2 = __shfl_xor(uh[a], o, COL_WAVE);
-                    ul[a] = l2 < ul[a] ? l2 : ul[a];
-                    uh[a] = h2 > uh[a] ? h2 : uh[a];
+                    ul[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[a]), 63));
+                    uh[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[3 + a]), 63));
                 }
+            } else {
+                ul[0] = wave_min_max<T, false>(lx); ul[1] = wave_min_max<T, false>(ly); ul[2] = wave_min_max<T, false>(lz);
+                uh[0] = wave_min_max<T, true>(hx); uh[1] = wave_min_max<T, true>(hy); uh[2] = wave_min_max<T, true>(hz);
             }
             const T mylo[3] = {lx, ly, lz}, myhi[3] = {hx, hy, hz};
             u32 qlo = 0, qhi = 0;
@@ -379,7 +433,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         // So the step is written for the scalar unit: a 32-bit record offset (one shift instead of shift + add +
         // addc; arrays below 4 GB), the six compares narrow EXEC (v_cmpx: lanes that fail drop out, the survivors
         // are the hits) instead of producing six masks to AND, and runs of misses -- more than half of all steps --
-        // stay inside one asm loop of 8 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
+        // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
         if (mode & 2) idx = END;
         if constexpr (sizeof(T) == 4 && OFF32 && !VEC) {
@@ -389,8 +443,9 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                 u64 hits;
                 u32 off;
                 v8i r;                       // the record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
-                asm volatile("1:\n\t"
-                             "s_lshl_b32 %[off], %[idx], 5\n\t"
+                asm volatile("s_mov_b32 s67, %[idx]\n"
+                             "1:\n\t"
+                             "s_lshl_b32 %[off], s67, 5\n\t"                 // s67: the node to fetch, then its skip link
                              "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
                              "v_cmpx_lt_f32_e32 vcc, s64, %[hx]\n\t"        // lo.x < my hi.x
@@ -401,12 +456,12 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
                              "s_cbranch_execnz 2f\n\t"                     // somebody overlaps: leave the loop
                              "s_mov_b64 exec, -1\n\t"
-                             "s_mov_b32 %[idx], s67\n\t"                   // nobody: follow the skip link
-                             "s_cmp_lg_u32 s67, -1\n\t"
+                             "s_cmp_lg_u32 s67, -1\n\t"                    // nobody: follow the skip link
                              "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 %[idx], -1\n\t"
                              "s_mov_b64 %[hits], 0\n\t"
                              "s_branch 3f\n"
-                             "2:\n\t"
+                             "2:\n\t"                                       // (%[off] / 32 is the node that was hit)
                              "s_mov_b64 %[hits], exec\n\t"
                              "s_mov_b64 exec, -1\n"
                              "3:"
@@ -415,7 +470,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              : "vcc", "scc", "memory");
                 if (!hits) break;                                           // the chain ended (idx == END)
                 const u32 skip = (u32)r[3], down = (u32)r[7];
-                if (idx >= leaf_start) { sink.emit(hits, qid, down); idx = skip; }
+                if (off >= leaf_start * 32u) { sink.emit(hits, qid, down); idx = skip; }      // a leaf record
                 else idx = down;
             }
         } else {
