@@ -300,7 +300,7 @@ def test_back_to_back_calls_on_a_clustered_scene(oracle, hip_env):
     cq.finish()
     for nb, pb in outs:
         assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == ref["count"]
-        assert pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2))) == pair_set(ref["pairs"])
+        assert_same_pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2)), ref["pairs"])
     assert collider.oversize_bucket > 8192 or collider._lsd_calls_left > 0      # reported, or already acted upon
     collider.get_collisions(cq, cb, rb, outs[0][0], outs[0][1], ref["count"])     # sees the word: LSD from here on
     assert collider._lsd_calls_left > 0
