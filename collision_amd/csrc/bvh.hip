@@ -439,9 +439,10 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         if constexpr (sizeof(T) == 4 && OFF32 && !VEC) {
             typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
+            const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
             while (idx != END) {
                 u64 hits;
-                u32 off;
+                u32 off, t0, v0, v1;
                 v8i r;                       // the record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
                 asm volatile("s_mov_b32 s67, %[idx]\n"
                              "1:\n\t"
@@ -454,24 +455,49 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "v_cmpx_gt_f32_e32 vcc, s69, %[ly]\n\t"
                              "v_cmpx_lt_f32_e32 vcc, s66, %[hz]\n\t"
                              "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
-                             "s_cbranch_execnz 2f\n\t"                     // somebody overlaps: leave the loop
+                             "s_cbranch_execnz 2f\n\t"                     // somebody overlaps
                              "s_mov_b64 exec, -1\n\t"
                              "s_cmp_lg_u32 s67, -1\n\t"                    // nobody: follow the skip link
                              "s_cbranch_scc1 1b\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
                              "s_mov_b64 %[hits], 0\n\t"
-                             "s_branch 3f\n"
-                             "2:\n\t"                                       // (%[off] / 32 is the node that was hit)
+                             "s_branch 4f\n"
+                             "2:\n\t"
+                             "s_cmp_ge_u32 %[off], %[leaf]\n\t"
+                             "s_cbranch_scc1 3f\n\t"
+                             "s_mov_b64 exec, -1\n\t"                      // an internal node: descend (down link) and go on
+                             "s_mov_b32 s67, s71\n\t"
+                             "s_branch 1b\n"
+                             "3:\n\t"                                       // a leaf: stage (my id, its id) for the hit lanes
+                             "s_bcnt1_i32_b64 %[t0], exec\n\t"
+                             "s_add_u32 %[t0], %[cnt], %[t0]\n\t"
+                             "s_cmp_gt_u32 %[t0], %[capw]\n\t"
+                             "s_cbranch_scc1 5f\n\t"                        // the staging area is full: let the sink flush it
+                             "v_mbcnt_lo_u32_b32 %[v0], exec_lo, 0\n\t"
+                             "v_mbcnt_hi_u32_b32 %[v0], exec_hi, %[v0]\n\t"
+                             "v_add_u32 %[v0], %[cnt], %[v0]\n\t"
+                             "v_lshl_add_u32 %[v0], %[v0], 3, %[buf]\n\t"
+                             "v_mov_b32 %[v1], s71\n\t"
+                             "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"
+                             "s_mov_b32 %[cnt], %[t0]\n\t"
+                             "s_mov_b64 exec, -1\n\t"
+                             "s_cmp_lg_u32 s67, -1\n\t"                    // and on along the leaf's skip link
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 %[idx], -1\n\t"
+                             "s_mov_b64 %[hits], 0\n\t"
+                             "s_branch 4f\n"
+                             "5:\n\t"
                              "s_mov_b64 %[hits], exec\n\t"
                              "s_mov_b64 exec, -1\n"
-                             "3:"
-                             : [idx] "+s"(idx), [hits] "=s"(hits), [off] "=&s"(off), "={s[64:71]}"(r)
-                             : [base] "s"(rows_b), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
+                             "4:"
+                             : [idx] "+s"(idx), [cnt] "+s"(sink.count), [hits] "=s"(hits), [off] "=&s"(off), [t0] "=&s"(t0),
+                               [v0] "=&v"(v0), [v1] "=&v"(v1), "={s[64:71]}"(r)
+                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [capw] "s"((u32)CAPW), [buf] "s"(buf_lds),
+                               [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
                              : "vcc", "scc", "memory");
                 if (!hits) break;                                           // the chain ended (idx == END)
-                const u32 skip = (u32)r[3], down = (u32)r[7];
-                if (off >= leaf_start * 32u) { sink.emit(hits, qid, down); idx = skip; }      // a leaf record
-                else idx = down;
+                sink.emit(hits, qid, (u32)r[7]);                             // (the staging area was full: flush, then stage)
+                idx = (u32)r[3];                                            // and on along the leaf's skip link
             }
         } else {
             auto test = [&](const V4 &a, const V4 &b) -> u64 {

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     __shared__ u32 s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
     __shared__ u32 s_ws[NW];
+    __shared__ u32 s_dstart[DIAG ? RDIG : 1];        // (diagnostics, mode 8192)
 
     const V *vals_in = reinterpret_cast<const V *>(vals_in_);
     V *vals_out = reinterpret_cast<V *>(vals_out_);
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
             for (int i = 0; i < NW; i++) { s_cnt[i][tid] = run; run += c[i]; }
             // global position of tile-sorted slot i with digit d is s_goff[d] + i
             s_goff[tid] = my_offset - dstart;
+            if (DIAG) s_dstart[tid] = dstart;
         }
     }
     __syncthreads();
@@ -331,6 +333,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
             if (DIAG) {
                 if (dbg & 2) g = (u32)tile_base + i;           // timing ablation: coalesced output
                 if (dbg & 32768) g &= (1u << 20) - 1;          // timing ablation: every store lands in a 4 MiB window (L2)
+                if (dbg & 8192) {      // timing ablation: every (tile, digit) run in a 128-byte cell of its own, digit-major
+                    const u32 d = digit_of(kk, shift);         // (same spatial pattern as the real runs, but whole aligned lines)
+                    g = (u32)(((u64)d * nblocks + b) * 32 + min(i - s_dstart[d], 31u));
+                }
             }
             if (DIAG && (dbg & 384)) {                         // timing ablations: stores at system (128) / agent (256) scope
                 if (dbg & 128) {

@@ -23,7 +23,8 @@ copy(); cq.finish()
 ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
 modes = ((0, "production"), (1 << 30, "production (diag instance)"), (2, "coalesced write"), (4, "blockIdx tile order"),
-         (64, "non-temporal loads"), (32768, "4 MiB output window (stores hit L2)"))
+         (64, "non-temporal loads"), (32768, "4 MiB output window (stores hit L2)"),
+         (8192, "every run an aligned 128-byte cell of its own"), (1024, "one resident block per CU (+18 KB LDS)"))
 if len(sys.argv) > 2:
     want = set(int(x) for x in sys.argv[2].split(","))
     modes = tuple(m for m in modes if m[0] in want)
