@@ -398,15 +398,20 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             const u32 qhi_c = qhi + CARRY;
             // Rotation schedule: lane q meets lane (q + r) mod 64 for r = 1..32, i.e. every unordered
             // pair of the packet exactly once (r = 32 pairs the two halves: only the lower half tests).
-            // 32 rounds of two wave shuffles; broadcasting candidates 1..63 with v_readlane instead
-            // takes 63 rounds in which half the lanes are idle (measured 0.107 vs 0.097 ms, 1 M spheres).
-            for (int r = 1; r <= 32; r++) {
+            // (Broadcasting candidates 1..63 with v_readlane instead takes 63 rounds in which half the lanes
+            // are idle: 0.107 vs 0.097 ms at 1 M spheres, round 1.)  The two screening words ROTATE through
+            // the wave one lane per round on the DPP network (wave_rol:1 -- lane i takes lane i + 1's value;
+            // one v_mov_dpp each, no LDS, no address arithmetic); the exact boxes are fetched by ds_bpermute
+            // only in rounds where the screen lets somebody through.
+            u32 rlo = qlo, rhi_c = qhi_c;
+            auto round = [&](int r, bool lower_half_only) {
+                rlo = (u32)__builtin_amdgcn_update_dpp((int)rlo, (int)rlo, 0x134, 0xF, 0xF, false);        // wave_rol:1
+                rhi_c = (u32)__builtin_amdgcn_update_dpp((int)rhi_c, (int)rhi_c, 0x134, 0xF, 0xF, false);
+                const u32 both = (qhi_c - rlo) & (rhi_c - qlo) & CARRY;     // my hi >= its lo, its hi >= my lo
+                bool hit = both == CARRY;
+                if (lower_half_only) hit = hit && lane < 32u;
+                if (!__builtin_amdgcn_ballot_w64(hit)) return;
                 const int pl = (int)((lane + r) & 63u);
-                const u32 p_lo = (u32)__shfl((int)qlo, pl, COL_WAVE);
-                const u32 p_hi_c = (u32)__shfl((int)qhi_c, pl, COL_WAVE);
-                const u32 both = (qhi_c - p_lo) & (p_hi_c - qlo) & CARRY;   // my hi >= its lo, its hi >= my lo
-                bool hit = both == CARRY && (r < 32 || lane < 32u);
-                if (!__builtin_amdgcn_ballot_w64(hit)) continue;
                 const T plx = __shfl(lx, pl, COL_WAVE), phx = __shfl(hx, pl, COL_WAVE);
                 const T ply = __shfl(ly, pl, COL_WAVE), phy = __shfl(hy, pl, COL_WAVE);
                 const T plz = __shfl(lz, pl, COL_WAVE), phz = __shfl(hz, pl, COL_WAVE);
@@ -415,7 +420,10 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                 const u64 hits = __builtin_amdgcn_ballot_w64(hit);
                 const bool mine_first = (int)lane < pl;                  // the earlier sorted leaf comes first
                 if (hits) sink.emit(hits, mine_first ? qid : pid, mine_first ? pid : qid);
-            }
+            };
+#pragma unroll 1
+            for (int r = 1; r < 32; r++) round(r, false);
+            round(32, true);
         }
 
         // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain: one
