@@ -121,27 +121,29 @@ template <typename T> __device__ __forceinline__ Box<T> gtab_query(const T *tab,
 // search run at LDS latency; probes outside the window fall back to global memory.
 constexpr int HALO = 256;
 constexpr int WIN = C + 2 * HALO;
-struct Codes {
+// I: the type of a (possibly out-of-range) leaf position in the Karras search: int32_t below 2^30 leaves --
+// i +- 2 * range cannot overflow it, and 32-bit index arithmetic is half the vector instructions -- else int64_t
+template <typename I> struct Codes {
     const u32 *__restrict__ g;
     const u32 *win;
-    int64_t w0;
+    I w0;
     u32 n;
-    __device__ __forceinline__ u32 at(int64_t j) const {
-        const int64_t o = j - w0;
+    __device__ __forceinline__ u32 at(I j) const {
+        const I o = j - w0;
         return (o >= 0 && o < WIN) ? win[o] : g[j];
     }
 };
 // collision.cl:65-77
-__device__ __forceinline__ int delta(const Codes &c, u32 i, u32 ci, int64_t j) {
-    if (j < 0 || j >= (int64_t)c.n) return -1;
+template <typename I> __device__ __forceinline__ int delta(const Codes<I> &c, u32 i, u32 ci, I j) {
+    if (j < 0 || j >= (I)c.n) return -1;
     const u32 cj = c.at(j);
     return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
 }
 // the right child that starts at leaf k (see bvh.hip)
-__device__ __forceinline__ u32 right_child_at(const Codes &c, u32 k) {
+template <typename I> __device__ __forceinline__ u32 right_child_at(const Codes<I> &c, u32 k) {
     if (k + 1 >= c.n) return (c.n - 1) + k;
-    const u32 ck = c.at(k);
-    const bool fwd = delta(c, k, ck, (int64_t)k + 1) > delta(c, k, ck, (int64_t)k - 1);
+    const u32 ck = c.at((I)k);
+    const bool fwd = delta(c, k, ck, (I)k + 1) > delta(c, k, ck, (I)k - 1);
     return fwd ? k : (c.n - 1) + k;
 }
 
@@ -208,7 +210,7 @@ template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
 __device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
 __device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
 
-template <typename T, bool DIAG>
+template <typename T, bool DIAG, typename I>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     const u32 chunk = blockIdx.x;
     const u32 c0 = chunk * C;
     const u32 p = c0 + tid;
-    Codes codes = {gcodes, s_codes, (int64_t)c0 - HALO, n};
+    Codes<I> codes = {gcodes, s_codes, (I)c0 - HALO, n};
     for (int o = tid; o < WIN; o += C) {
-        const int64_t j = codes.w0 + o;
-        s_codes[o] = (j >= 0 && j < (int64_t)n) ? gcodes[j] : 0u;
+        const I j = codes.w0 + o;
+        s_codes[o] = (j >= 0 && j < (I)n) ? gcodes[j] : 0u;
     }
     lds.ready[tid] = 0;
     const u32 leaf_start = n - 1;
@@ -281,20 +283,20 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (p >= leaf_start || (dbg & 4)) return;                      // no barrier below this line
 
     // internal node p: collision.cl:81-121 (Karras 2012)
-    const u32 i = p, ci = codes.at(i);
-    const int dir = delta(codes, i, ci, (int64_t)i + 1) > delta(codes, i, ci, (int64_t)i - 1) ? 1 : -1;
-    const int delta_min = delta(codes, i, ci, (int64_t)i - dir);
-    int64_t len_max = 2;
-    while (delta(codes, i, ci, (int64_t)i + dir * len_max) > delta_min) len_max *= 2;
-    int64_t len = 0;
-    for (int64_t t = len_max / 2; t > 0; t /= 2)
-        if (delta(codes, i, ci, (int64_t)i + dir * (len + t)) > delta_min) len += t;
-    const u32 j = (u32)((int64_t)i + dir * len);
-    const int delta_node = delta(codes, i, ci, (int64_t)j);
-    int64_t s = 0, t = len;
+    const u32 i = p, ci = codes.at((I)i);
+    const int dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
+    const int delta_min = delta(codes, i, ci, (I)i - dir);
+    I len_max = 2;
+    while (delta(codes, i, ci, (I)i + dir * len_max) > delta_min) len_max *= 2;
+    I len = 0;
+    for (I t = len_max / 2; t > 0; t /= 2)
+        if (delta(codes, i, ci, (I)i + dir * (len + t)) > delta_min) len += t;
+    const u32 j = (u32)((I)i + dir * len);
+    const int delta_node = delta(codes, i, ci, (I)j);
+    I s = 0, t = len;
     do {
         t = (t + 1) / 2;
-        if (delta(codes, i, ci, (int64_t)i + dir * (s + t)) > delta_node) s += t;
+        if (delta(codes, i, ci, (I)i + dir * (s + t)) > delta_node) s += t;
     } while (t > 1);
     const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
     const u32 lo = min(i, j), hi = max(i, j);
@@ -423,11 +425,14 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
     if (g_dbg)
-        k_chunk<T, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                           (T *)tabs.t[0], n, ChunkDiagOn{g_dbg});
+        k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+                                                                    (T *)tabs.t[0], n, ChunkDiagOn{g_dbg});
+    else if (n < (1u << 30))
+        k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+                                                                     (T *)tabs.t[0], n, ChunkDiagOff{});
     else
-        k_chunk<T, false><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                            (T *)tabs.t[0], n, ChunkDiagOff{});
+        k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+                                                                     (T *)tabs.t[0], n, ChunkDiagOff{});
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
     int lin = -1;
