@@ -463,7 +463,9 @@ def main():
         pair_count = int(hip.read_buffer(cq, n_buf, np.uint32, 1)[0])
     else:
         pair_count = engine.global_pair_count()
-        extra["per_rank"] = {"owned_spheres_rank0": engine.stats.get("owned"), "ghost_queries_rank0": engine.stats.get("ghosts")}
+        extra["per_rank"] = {"owned_spheres_rank0": engine.stats.get("owned"), "ghost_queries_rank0": engine.stats.get("ghosts"),
+                             "partition_slot_records": engine.stats.get("partition_slot"),
+                             "halo_slot_records": engine.stats.get("halo_slot"), "repeated_steps": engine.repeats}
         # the same protocol at 1 M spheres per rank (round 1's line), reported beside the config-4 workload
         del engine
         engine1 = make_engine(N_SPHERES)

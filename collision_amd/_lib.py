@@ -80,15 +80,20 @@ _PROTOS = {
     "col_collide": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_uint32]),
-    "col_sample_rows": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
-    "col_fold_boxes_strided": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
-    "col_splitters_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_bucketize_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
-    "col_digit_counts": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_pack_records": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
-    "col_unpack_records": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_partition_scratch_bytes": (C.c_size_t, []),
+    "col_partition_sample": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_uint32, C.c_int]),
+    "col_partition_plan": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_partition_group": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_partition_unpack": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_int]),
     "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
-    "col_region_box": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_region_boxes": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_uint32, C.c_int]),
     "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]),
     "col_pack_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,

@@ -38,6 +38,7 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 #define COL_MINMAX_PARTS 256
 // col_radix_sort_msd: one workgroup finishes one of 256 top-digit buckets in LDS -- 8192 pairs per bucket for
 // inputs up to COL_MSD_SMALL_N codes, 16384 up to COL_MSD_MAX_N (uniform scenes: n / 256 per bucket +- 4 sigma)
+#define COL_REGION_BOXES 8      /* boxes per rank region on the multi-GPU path (multi.hip: k_region) */
 #define COL_MSD_SMALL_N 1900000u
 #define COL_MSD_MAX_N 4050000u
 extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
@@ -101,4 +102,32 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *warp_sums, u32 *total
     *total = tot;
     return base + incl - v;
 }
+// ---- 30-bit Morton codes (collision.cl:14-31); shared by morton.hip and multi.hip ----
+__device__ __forceinline__ u32 expand_bits(u32 v) {   // collision.cl:14-20
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+template <typename T> __device__ __forceinline__ T tmax(T a, T b);
+template <> __device__ __forceinline__ float tmax(float a, float b) { return fmaxf(a, b); }
+template <> __device__ __forceinline__ double tmax(double a, double b) { return fmax(a, b); }
+template <typename T> __device__ __forceinline__ T tmin(T a, T b);
+template <> __device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
+template <> __device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
+// collision.cl:22-31: q = (uint) clamp(((p - min) / (max - min)) * 1023, 0, 1023); NaN -> 0.
+template <typename T>
+__device__ __forceinline__ u32 quantize(T p, T mn, T mx) {
+    T t = (p - mn) / (mx - mn);
+    t = t * (T)1023;
+    t = tmin(tmax(t, (T)0), (T)1023);
+    return (u32)t;
+}
+template <typename T>
+__device__ __forceinline__ u32 morton30(T x, T y, T z, T mnx, T mny, T mnz, T mxx, T mxy, T mxz) {
+    return (expand_bits(quantize(x, mnx, mxx)) << 2) + (expand_bits(quantize(y, mny, mxy)) << 1) +
+           expand_bits(quantize(z, mnz, mxz));
+}
 #endif
+

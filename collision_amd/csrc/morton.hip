@@ -9,32 +9,10 @@
 
 namespace {
 
-__device__ __forceinline__ u32 expand_bits(u32 v) {   // collision.cl:14-20
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
+// expand_bits / quantize (collision.cl:14-31) live in col_common.h: multi.hip computes the same codes
 
 template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T x, y, z, w; };
 template <> struct alignas(16) Vec4<double> { double x, y, z, w; };
-
-template <typename T> __device__ __forceinline__ T tmax(T a, T b);
-template <> __device__ __forceinline__ float tmax(float a, float b) { return fmaxf(a, b); }
-template <> __device__ __forceinline__ double tmax(double a, double b) { return fmax(a, b); }
-template <typename T> __device__ __forceinline__ T tmin(T a, T b);
-template <> __device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
-template <> __device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
-
-// collision.cl:22-31: q = (uint) clamp(((p - min) / (max - min)) * 1023, 0, 1023); NaN -> 0.
-template <typename T>
-__device__ __forceinline__ u32 quantize(T p, T mn, T mx) {
-    T t = (p - mn) / (mx - mn);
-    t = t * (T)1023;
-    t = tmin(tmax(t, (T)0), (T)1023);
-    return (u32)t;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coords,

@@ -3,12 +3,14 @@
 // repartition, halo exchange) are RCCL calls made by the host code in collision_amd/multi.py; the
 // kernels here prepare and consume the exchanged buffers, for f32 and f64 coordinates (coord_bytes):
 //
-//   col_sample_rows          a rank's contribution to the splitter sample
-//   col_fold_boxes_strided   gathered [min row, max row] boxes -> the global scene range
-//   col_splitters_u32        world - 1 quantiles of the gathered samples' Morton codes
-//   col_bucketize_u32        owner rank of every Morton code; col_digit_counts: spheres per owner
-//   col_pack_records / col_unpack_records   transport records (x, y, z, r, global id)
-//   col_region_box           a conservative box around everything a rank owns
+//   col_partition_sample     a rank's contribution to the splitter sample + its centre range (ONE launch)
+//   col_partition_plan       gathered samples -> global range, splitters; owner of every sphere; the
+//                            per-tile owner histogram, scanned; spheres per owner   (3 launches)
+//   col_partition_group      stable grouping by owner (one radix scatter) and packing: the spheres this
+//                            rank keeps go straight into its owned arrays, the others into one fixed-size
+//                            slot of transport records (x, y, z, r, global id) per peer   (2 launches)
+//   col_partition_unpack     received slots -> owned arrays; publishes the owned count to the host
+//   col_region_boxes         a rank's region: conservative boxes around what it owns, one per scene octant
 //   col_select_overlap_multi the halo lists: owned spheres whose box overlaps a peer's region
 //   col_pack_slots           the lists as fixed-size slots with a length header
 //   col_traverse_ghost_slots received spheres as QUERIES against the local LBVH (never inserted);
@@ -56,33 +58,15 @@ template <typename T> __device__ __forceinline__ typename MT<T>::V4 rec_load(con
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack_records(const typename MT<T>::V4 *__restrict__ rows, const u32 *__restrict__ gids,
-                                                       const u32 *__restrict__ idx, u32 n, u32 *__restrict__ rec) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u32 s = idx ? idx[i] : i;
-    rec_store<T>(rec + (u64)MT<T>::RW * i, rows[s], gids ? gids[s] : s);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void k_unpack_records(const u32 *__restrict__ rec, u32 n, typename MT<T>::V4 *__restrict__ rows,
-                                                         u32 *__restrict__ gids, T *__restrict__ radii) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    u32 gid;
-    const typename MT<T>::V4 c = rec_load<T>(rec + (u64)MT<T>::RW * i, &gid);
-    rows[i] = c;
-    gids[i] = gid;
-    if (radii) radii[i] = c.w;
-}
-template <typename T>
 __global__ __launch_bounds__(256) void k_unpack_radii(const typename MT<T>::V4 *__restrict__ rows, u32 n, T *__restrict__ radii) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) radii[i] = rows[i].w;
 }
 
-// Halo selection against up to 8 peer boxes in one launch: list[k] collects the indices of the
-// spheres overlapping the region box of peer q[k], counts[k] their number.  The boxes stay on the
-// device (they come straight out of the AABB all-gather): no host round trip.
+// Halo selection for up to 8 peers in one launch: list[k] collects the indices of the spheres overlapping the
+// REGION of peer q[k], counts[k] their number.  A region is COL_REGION_BOXES boxes (k_region: one per octant of
+// the scene, empty ones inverted); they stay on the device (straight out of the AABB all-gather): no host
+// round trip.
 struct PeerList { int q[8]; int n; };
 template <typename T>
 __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *__restrict__ rows, u32 n,
@@ -94,9 +78,15 @@ __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *
     if (i < n) c = rows[i];
     const u32 lane = lane_id();
     for (int k = 0; k < pl.n; k++) {
-        const typename MT<T>::V4 lo = boxes[2 * pl.q[k]], hi = boxes[2 * pl.q[k] + 1];      // wave-uniform
-        const bool hit = i < n && c.x + c.w > lo.x && c.x - c.w < hi.x && c.y + c.w > lo.y && c.y - c.w < hi.y &&
-                         c.z + c.w > lo.z && c.z - c.w < hi.z;               // strict, as collision.cl:164-166
+        bool hit = false;
+        const typename MT<T>::V4 *region = boxes + 2 * COL_REGION_BOXES * pl.q[k];      // wave-uniform
+#pragma unroll
+        for (int o = 0; o < COL_REGION_BOXES; o++) {
+            const typename MT<T>::V4 lo = region[2 * o], hi = region[2 * o + 1];
+            hit |= c.x + c.w > lo.x && c.x - c.w < hi.x && c.y + c.w > lo.y && c.y - c.w < hi.y &&
+                   c.z + c.w > lo.z && c.z - c.w < hi.z;                      // strict, as collision.cl:164-166
+        }
+        hit = hit && i < n;
         const u64 hits = __ballot(hit);
         if (!hits) continue;
         const int leader = (int)__builtin_ctzll(hits);
@@ -125,23 +115,6 @@ __global__ __launch_bounds__(256) void k_pack_slots(const typename MT<T>::V4 *__
         const u32 s = lists[(uint64_t)k * stride + i];
         rec_store<T>(base + (u64)RW * (1 + i), rows[s], gids[s]);
     }
-}
-
-// destination rank of a Morton code: number of splitters <= code (splitters sorted, <= 255 of them)
-__global__ __launch_bounds__(256) void k_bucketize(const u32 *__restrict__ codes, u32 n, const u32 *__restrict__ splitters,
-                                                    u32 n_split, u32 *__restrict__ dest) {
-    __shared__ u32 sp[256];
-    if (threadIdx.x < n_split) sp[threadIdx.x] = splitters[threadIdx.x];
-    __syncthreads();
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u32 c = codes[i];
-    u32 lo = 0, hi = n_split;                // first index with sp[idx] > c
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (sp[mid] <= c) lo = mid + 1; else hi = mid;
-    }
-    dest[i] = lo;
 }
 
 // Ghost spheres as queries: a lane-per-ghost walk from the root over the node records (box + skip/down
@@ -222,54 +195,233 @@ __global__ __launch_bounds__(256) void k_translate(u32 *__restrict__ pairs, cons
         pairs[i] = gids[pairs[i]];
 }
 
-// ---- small protocol steps (one launch each instead of chains of tensor-library calls) ----
+// ---- the repartition (Morton ranges of equal population), a few launches between the collectives ----
 
-// fold `count` gathered [min row, max row] boxes (`stride` scalars apart) into one
+// min / max over the wave of 8 scalars (4 minima, 4 maxima)
+template <typename T> __device__ __forceinline__ void wave_fold8(T (&v)[8]) {
+#pragma unroll
+    for (int o = COL_WAVE / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const T t = __shfl_xor(v[k], o, COL_WAVE);
+            v[k] = k < 4 ? (t < v[k] ? t : v[k]) : (t > v[k] ? t : v[k]);
+        }
+}
+
+// [min row, max row] of rows[0..n) in two launches (a single launch that lets the last block fold the partials
+// needs agent-scope fences, and on this part those write back and invalidate the whole L2 under the blocks that
+// are still streaming: measured 22 us against 8 + 3 for the pair).  k_range_part: one partial per block.
+constexpr int SR_BLOCKS = 256, RU = 4;
 template <typename T>
-__global__ __launch_bounds__(64) void k_fold_boxes(const T *__restrict__ boxes, u32 count, u32 stride, T *__restrict__ out) {
-    const u32 k = threadIdx.x;
-    if (k >= 8) return;
-    T acc = k < 4 ? (T)INFINITY : -(T)INFINITY;
-    for (u32 i = 0; i < count; i++) {
-        const T v = boxes[(u64)stride * i + k];
-        acc = k < 4 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+__global__ __launch_bounds__(256) void k_range_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, T *__restrict__ partials) {
+    typedef typename MT<T>::V4 V4;
+    __shared__ T s_part[4][8];
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
+    T v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = k < 4 ? (T)INFINITY : -(T)INFINITY;
+    // RU rows in flight per thread: the loop is bound by the latency of its loads, not by their bytes
+    const u32 stride = gridDim.x * 256;
+    for (u32 i0 = blockIdx.x * 256 + tid; i0 < n; i0 += RU * stride) {
+        V4 c[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) c[u] = rows[min(i0 + u * stride, n - 1)];      // (a repeated row changes no min / max)
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const T e[4] = {c[u].x, c[u].y, c[u].z, c[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = e[k] < v[k] ? e[k] : v[k];
+                v[4 + k] = e[k] > v[4 + k] ? e[k] : v[4 + k];
+            }
+        }
     }
-    out[k] = acc;
+    wave_fold8(v);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_part[w][k] = v[k];
+    __syncthreads();
+    if (tid < 8) {
+        T a = s_part[0][tid];
+        for (int i = 1; i < 4; i++) { const T t = s_part[i][tid]; a = tid < 4 ? (t < a ? t : a) : (t > a ? t : a); }
+        partials[(u64)blockIdx.x * 8 + tid] = a;
+    }
 }
-
-// `samples` evenly strided ROWS (x, y, z, r) of rows[0..n): what a rank contributes to the splitter
-// sample (the rows are in id-hash order: a strided sample is a random sample); an empty rank
-// contributes rows at +infinity (their codes clamp to the ceiling)
+// k_range_fold: out = `samples` evenly strided rows (an empty rank: rows at +infinity), then the min row, then the
+// max row (block 0 folds the `parts` partials; min / max are exact and order-independent): what a rank contributes
+// to the splitter sample (the rows arrive in id-hash order, so a strided sample is a random one).  Also clears
+// the `zero_count` words at `zero` (the step's flags: no fill launch).
 template <typename T>
-__global__ __launch_bounds__(256) void k_sample_rows(const typename MT<T>::V4 *__restrict__ rows, u32 n, u32 samples,
-                                                      typename MT<T>::V4 *__restrict__ out) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= samples) return;
-    typename MT<T>::V4 v;
-    v.x = v.y = v.z = (T)INFINITY; v.w = (T)0;
-    if (n) v = rows[samples > 1 ? (u32)(((u64)i * (n - 1)) / (samples - 1)) : 0u];
-    out[i] = v;
+__global__ __launch_bounds__(256) void k_range_fold(const typename MT<T>::V4 *__restrict__ rows, u32 n, u32 samples,
+                                                     const T *__restrict__ partials, u32 parts,
+                                                     typename MT<T>::V4 *__restrict__ out, u32 *__restrict__ zero, u32 zero_count) {
+    typedef typename MT<T>::V4 V4;
+    __shared__ T s_fold[32][8];
+    const u32 tid = threadIdx.x;
+    const u32 i = blockIdx.x * 256 + tid;
+    if (i < samples) {
+        V4 v;
+        v.x = v.y = v.z = (T)INFINITY; v.w = (T)0;
+        if (n) v = rows[samples > 1 ? (u32)(((u64)i * (n - 1)) / (samples - 1)) : 0u];
+        out[i] = v;
+    }
+    if (blockIdx.x != 0) return;
+    if (tid < zero_count) zero[tid] = 0;
+    {                                               // 256 threads = 32 slices of the partials x 8 columns, loads in flight together
+        const u32 col = tid & 7u, part = tid >> 3;
+        T a = col < 4 ? (T)INFINITY : -(T)INFINITY;
+#pragma unroll
+        for (int j = 0; j < SR_BLOCKS / 32; j++) {
+            const u32 b = part + 32u * j;
+            if (b < parts) { const T t = partials[(u64)b * 8 + col]; a = col < 4 ? (t < a ? t : a) : (t > a ? t : a); }
+        }
+        s_fold[part][col] = a;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        T a = s_fold[0][tid];
+        for (int k = 1; k < 32; k++) { const T t = s_fold[k][tid]; a = tid < 4 ? (t < a ? t : a) : (t > a ? t : a); }
+        reinterpret_cast<T *>(out + samples)[tid] = a;      // the min row, then the max row
+    }
 }
 
-// [min row, max row] of (x, y, z, r) rows -> a box that contains every sphere: (min centre - max r,
-// max centre + max r).  Conservative (exact for equal radii), which is all a halo selection needs.
+// The REGION of a rank for the halo selection: COL_REGION_BOXES = 8 boxes, one per octant of the global scene range
+// (the top three bits of a sphere's Morton code), each (min centre - max r, 0, max centre + max r, 0) over the owned
+// spheres of that octant -- conservative (exact for equal radii), which is all a halo selection needs; an octant
+// without spheres gets an inverted box that nothing overlaps.  A rank owns a Morton RANGE: inside one octant that
+// is a compact piece, while ONE box around a range that spills over an octant boundary by a few spheres would
+// cover a quarter of the scene.  range8 == NULL (no repartition): everything counts as octant 0.
+// Two launches like k_range (partials: 56 scalars per block); the fold also clears zero[0..zero_count).
+constexpr int RG_VALS = 7 * COL_REGION_BOXES;      // per octant: min x, y, z; max x, y, z; max r
 template <typename T>
-__global__ __launch_bounds__(64) void k_region_box(const T *__restrict__ minmax, T *__restrict__ out) {
-    const u32 k = threadIdx.x;
-    if (k >= 8) return;
-    const T rmax = minmax[7];
-    out[k] = (k & 3) == 3 ? (T)0 : (k < 4 ? minmax[k] - rmax : minmax[k] + rmax);
+__global__ __launch_bounds__(256) void k_region_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
+                                                      T *__restrict__ partials) {
+    typedef typename MT<T>::V4 V4;
+    __shared__ T s_part[4][RG_VALS];
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
+    T v[COL_REGION_BOXES][7];
+#pragma unroll
+    for (int o = 0; o < COL_REGION_BOXES; o++)
+#pragma unroll
+        for (int k = 0; k < 7; k++) v[o][k] = k < 3 ? (T)INFINITY : -(T)INFINITY;
+    T mnx = 0, mny = 0, mnz = 0, mxx = 1, mxy = 1, mxz = 1;
+    if (range8) { mnx = range8[0]; mny = range8[1]; mnz = range8[2]; mxx = range8[4]; mxy = range8[5]; mxz = range8[6]; }
+    const u32 stride = gridDim.x * 256;
+    for (u32 i0 = blockIdx.x * 256 + tid; i0 < n; i0 += RU * stride) {
+        V4 cc[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) cc[u] = rows[min(i0 + u * stride, n - 1)];     // (a repeated row changes no min / max)
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const V4 c = cc[u];
+            const u32 oct = range8 ? morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz) >> 27 : 0u;
+            const T e[3] = {c.x, c.y, c.z};
+#pragma unroll
+            for (int o = 0; o < COL_REGION_BOXES; o++)
+                if (oct == (u32)o) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        v[o][k] = e[k] < v[o][k] ? e[k] : v[o][k];
+                        v[o][3 + k] = e[k] > v[o][3 + k] ? e[k] : v[o][3 + k];
+                    }
+                    v[o][6] = c.w > v[o][6] ? c.w : v[o][6];
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COL_REGION_BOXES; o++)
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            T a = v[o][k];
+#pragma unroll
+            for (int d = COL_WAVE / 2; d > 0; d >>= 1) {
+                const T t = __shfl_xor(a, d, COL_WAVE);
+                a = k < 3 ? (t < a ? t : a) : (t > a ? t : a);
+            }
+            if (lane == 0) s_part[w][o * 7 + k] = a;
+        }
+    __syncthreads();
+    if (tid < (u32)RG_VALS) {
+        const bool is_min = tid % 7 < 3;
+        T a = s_part[0][tid];
+        for (int i = 1; i < 4; i++) { const T t = s_part[i][tid]; a = is_min ? (t < a ? t : a) : (t > a ? t : a); }
+        partials[(u64)blockIdx.x * RG_VALS + tid] = a;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_region_fold(const T *__restrict__ partials, u32 parts, typename MT<T>::V4 *__restrict__ out,
+                                                      u32 *__restrict__ zero, u32 zero_count) {
+    typedef typename MT<T>::V4 V4;
+    __shared__ T s_part[4][RG_VALS];
+    __shared__ T s_all[RG_VALS];
+    const u32 tid = threadIdx.x;
+    if (tid < zero_count) zero[tid] = 0;
+    if (tid < 4u * RG_VALS) {                      // 4 slices of the partials x 56 columns, 16 loads in flight per thread
+        const u32 col = tid % RG_VALS, part = tid / RG_VALS;
+        const bool is_min = col % 7 < 3;
+        T a = is_min ? (T)INFINITY : -(T)INFINITY;
+        for (u32 b0 = part; b0 < parts; b0 += 64) {
+            T t[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const u32 b = b0 + 4u * j;
+                t[j] = partials[(u64)(b < parts ? b : b0) * RG_VALS + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) a = is_min ? (t[j] < a ? t[j] : a) : (t[j] > a ? t[j] : a);
+        }
+        s_part[part][col] = a;
+    }
+    __syncthreads();
+    if (tid < (u32)RG_VALS) {
+        const bool is_min = tid % 7 < 3;
+        T a = s_part[0][tid];
+        for (int i = 1; i < 4; i++) { const T t = s_part[i][tid]; a = is_min ? (t < a ? t : a) : (t > a ? t : a); }
+        s_all[tid] = a;
+    }
+    __syncthreads();
+    if (tid < (u32)COL_REGION_BOXES) {
+        const T *a = s_all + tid * 7;
+        const T r = a[6];                       // (an empty octant: +inf - (-inf) = +inf, -inf + (-inf) = -inf)
+        V4 lo, hi;
+        lo.x = a[0] - r; lo.y = a[1] - r; lo.z = a[2] - r; lo.w = (T)0;
+        hi.x = a[3] + r; hi.y = a[4] + r; hi.z = a[5] + r; hi.w = (T)0;
+        out[2 * tid] = lo; out[2 * tid + 1] = hi;
+    }
 }
 
-// world - 1 splitters = quantiles of the `count` gathered samples (count <= SPL_MAX): one block sorts
-// them in LDS (bitonic) and picks every (count / world)-th
+// One block: the global scene range (fold of every rank's [min row, max row]) -> range8; the Morton codes
+// of ALL gathered rows (world x (samples + 2), at most SPL_MAX) under that range, sorted in LDS (bitonic);
+// splitter q = the code at position q * count / world.
 constexpr u32 SPL_MAX = 16384;
-__global__ __launch_bounds__(1024) void k_splitters(const u32 *__restrict__ samples, u32 count, u32 world,
-                                                     u32 *__restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(1024) void k_splitters(const typename MT<T>::V4 *__restrict__ gathered, u32 world, u32 samples,
+                                                     T *__restrict__ range8, u32 *__restrict__ splitters) {
+    typedef typename MT<T>::V4 V4;
     __shared__ u32 s[SPL_MAX];
+    __shared__ T s_range[8];
+    const u32 per = samples + 2, count = world * per;
+    if (threadIdx.x < 8) {
+        const u32 k = threadIdx.x;
+        T acc = k < 4 ? (T)INFINITY : -(T)INFINITY;
+        for (u32 q = 0; q < world; q++) {
+            const T v = reinterpret_cast<const T *>(gathered + (u64)q * per + samples + (k >> 2))[k & 3];
+            acc = k < 4 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+        }
+        s_range[k] = acc;
+        range8[k] = acc;
+    }
+    __syncthreads();
     u32 m = 1;
     while (m < count) m <<= 1;
-    for (u32 i = threadIdx.x; i < m; i += 1024) s[i] = i < count ? samples[i] : 0xFFFFFFFFu;
+    for (u32 i = threadIdx.x; i < m; i += 1024) {
+        u32 code = 0xFFFFFFFFu;
+        if (i < count) {
+            const V4 c = gathered[i];
+            code = morton30<T>(c.x, c.y, c.z, s_range[0], s_range[1], s_range[2], s_range[4], s_range[5], s_range[6]);
+        }
+        s[i] = code;
+    }
     __syncthreads();
     for (u32 k = 2; k <= m; k <<= 1) {
         for (u32 j = k >> 1; j > 0; j >>= 1) {
@@ -285,17 +437,151 @@ __global__ __launch_bounds__(1024) void k_splitters(const u32 *__restrict__ samp
         }
     }
     const u32 step = count / world;
-    for (u32 q = threadIdx.x + 1; q < world; q += 1024) out[q - 1] = s[q * step];
+    for (u32 q = threadIdx.x + 1; q < world; q += 1024) splitters[q - 1] = s[q * step];
 }
 
-// spheres per destination from the SCANNED digit-major histogram of the owner pass: the run of digit q
-// starts at scanned[q * nb]
-__global__ __launch_bounds__(256) void k_digit_counts(const u32 *__restrict__ scanned, u32 nb, u32 world, u32 n,
-                                                       u32 *__restrict__ out) {
-    const u32 q = threadIdx.x;
-    if (q >= world) return;
-    const u32 lo = scanned[(u64)q * nb], hi = q + 1 < 256 ? scanned[(u64)(q + 1) * nb] : n;
-    out[q] = hi - lo;
+// One block per tile of the radix scatter that groups the spheres by owner: Morton code of every row under the
+// global range, its owner (the number of splitters <= code), and the tile's owner histogram in the digit-major
+// layout of radix.hip (hist[owner * nblocks + tile]) -- the code itself is never stored.
+template <typename T>
+__global__ __launch_bounds__(256) void k_owners(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
+                                                 const u32 *__restrict__ splitters, u32 world, u32 tile, u32 nblocks,
+                                                 u32 *__restrict__ dest, u32 *__restrict__ hist) {
+    typedef typename MT<T>::V4 V4;
+    __shared__ u32 sp[256];
+    __shared__ u32 h[256];
+    const u32 tid = threadIdx.x, lane = lane_id();
+    if (tid + 1 < world) sp[tid] = splitters[tid];
+    h[tid] = 0;
+    const T mnx = range8[0], mny = range8[1], mnz = range8[2], mxx = range8[4], mxy = range8[5], mxz = range8[6];
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * tile;
+    for (u32 o = tid; o < tile; o += 256) {
+        const u64 i = base + o;
+        u32 q = 0xFFFFFFFFu;
+        if (i < n) {
+            const V4 c = rows[i];
+            const u32 code = morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz);
+            u32 lo = 0, hi = world - 1;              // first index with sp[idx] > code
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (sp[mid] <= code) lo = mid + 1; else hi = mid;
+            }
+            q = lo;
+            dest[i] = q;
+        }
+        if (world <= 16) {                          // few owners: one ballot per owner instead of 64 atomics on 8 words
+            for (u32 d = 0; d < world; d++) {
+                const u64 m = __ballot(q == d);
+                if (m && lane == 0) atomicAdd(&h[d], (u32)__popcll(m));
+            }
+        } else if (i < n) atomicAdd(&h[q], 1u);
+    }
+    __syncthreads();
+    if (tid < world) hist[(u64)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+// One block: exclusive scan, in place, of the first world * nblocks entries of the digit-major owner histogram
+// (the other digits do not occur) + the number of spheres per owner.
+__global__ __launch_bounds__(1024) void k_owner_offsets(u32 *__restrict__ hist, u32 nblocks, u32 world, u32 *__restrict__ counts) {
+    __shared__ u32 s_warp[16];
+    __shared__ u32 s_start[257];
+    const u32 e = world * nblocks, chunk = (e + 1023) / 1024;
+    const u32 lo = min(threadIdx.x * chunk, e), hi = min(lo + chunk, e);
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += hist[i];
+    u32 total;
+    u32 run = block_excl_scan<1024>(sum, s_warp, &total);
+    for (u32 i = lo; i < hi; i++) {
+        const u32 v = hist[i];
+        hist[i] = run;
+        if (i % nblocks == 0) s_start[i / nblocks] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) s_start[world] = total;
+    __syncthreads();
+    if (threadIdx.x < world) counts[threadIdx.x] = s_start[threadIdx.x + 1] - s_start[threadIdx.x];
+}
+
+// After the stable grouping (position i holds sphere perm[i] of owner owners[i]): the spheres this rank keeps go
+// straight to the front of its owned arrays; the others into the slot of their owner -- a header record whose
+// first word is the full length of the list, then min(length, slot) transport records.  A list longer than the
+// slot is visible to both sides in the header and is reported in flags[2] (longest list seen).
+template <typename T>
+__global__ __launch_bounds__(256) void k_partition_pack(const typename MT<T>::V4 *__restrict__ rows, const u32 *__restrict__ gids,
+                                                         const u32 *__restrict__ perm, const u32 *__restrict__ owners,
+                                                         const u32 *__restrict__ counts, u32 n, u32 world, u32 rank, u32 slot,
+                                                         u32 *__restrict__ send, typename MT<T>::V4 *__restrict__ own_rows,
+                                                         u32 *__restrict__ own_gids, T *__restrict__ own_radii,
+                                                         u32 *__restrict__ flags) {
+    constexpr int RW = MT<T>::RW;
+    __shared__ u32 s_warp[4];
+    __shared__ u32 s_start[256];
+    const u32 tid = threadIdx.x;
+    const u32 cnt = tid < world ? counts[tid] : 0u;
+    u32 total;
+    s_start[tid] = block_excl_scan<256>(cnt, s_warp, &total);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < world && tid != rank) {
+        u32 *hdr = send + (u64)RW * (tid < rank ? tid : tid - 1) * (slot + 1);
+        for (int k = 0; k < RW; k++) hdr[k] = k == 0 ? cnt : 0u;
+        if (cnt) atomicMax(&flags[2], cnt);
+    }
+    const u32 i = blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    const u32 q = owners[i], pos = i - s_start[q], src = perm[i];
+    const typename MT<T>::V4 c = rows[src];
+    const u32 gid = gids[src];
+    if (q == rank) {
+        own_rows[pos] = c;
+        own_gids[pos] = gid;
+        own_radii[pos] = c.w;
+    } else if (pos < slot)
+        rec_store<T>(send + (u64)RW * ((u64)(q < rank ? q : q - 1) * (slot + 1) + 1 + pos), c, gid);
+}
+
+// Received slots (blockIdx.y = slot of the k-th other rank, in rank order) -> the owned arrays, behind the
+// spheres the rank kept; block (0, 0) publishes the owned count: owned[0] = min(m, capacity), owned[1] = m, and
+// (sequence number << 32 | m) into a host-visible word, which is all the host waits for before it sizes the
+// local pipeline.
+template <typename T>
+__global__ __launch_bounds__(256) void k_partition_unpack(const u32 *__restrict__ recv, u32 world, u32 rank, u32 slot,
+                                                           const u32 *__restrict__ counts, typename MT<T>::V4 *__restrict__ own_rows,
+                                                           u32 *__restrict__ own_gids, T *__restrict__ own_radii, u32 capacity,
+                                                           u32 *__restrict__ owned, unsigned long long *host_word, u32 seq,
+                                                           u32 *__restrict__ flags) {
+    constexpr int RW = MT<T>::RW;
+    __shared__ u32 s_warp[4];
+    __shared__ u32 s_off[256], s_len[256];
+    const u32 tid = threadIdx.x, others = world - 1;
+    const u32 len = tid < others ? recv[(u64)RW * tid * (slot + 1)] : 0u;
+    u32 total;
+    s_off[tid] = block_excl_scan<256>(min(len, slot), s_warp, &total);
+    s_len[tid] = len;
+    __syncthreads();
+    const u32 kept = counts[rank];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < others && len) atomicMax(&flags[2], len);
+        if (tid == 0) {
+            const u64 m = (u64)kept + total;
+            owned[0] = (u32)(m < capacity ? m : capacity);
+            owned[1] = (u32)(m < 0xFFFFFFFFull ? m : 0xFFFFFFFFull);
+            if (host_word)
+                __hip_atomic_store(host_word, ((u64)seq << 32) | owned[1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (blockIdx.y >= others) return;
+    const u32 k = blockIdx.y, cnt = min(s_len[k], slot);
+    const u32 *base = recv + (u64)RW * ((u64)k * (slot + 1) + 1);
+    for (u32 i = blockIdx.x * 256 + tid; i < cnt; i += gridDim.x * 256) {
+        const u64 dst = (u64)kept + s_off[k] + i;
+        if (dst >= capacity) break;
+        u32 gid;
+        const typename MT<T>::V4 c = rec_load<T>(base + (u64)RW * i, &gid);
+        own_rows[dst] = c;
+        own_gids[dst] = gid;
+        own_radii[dst] = c.w;
+    }
 }
 
 inline unsigned blocks_for(uint64_t n) { return (unsigned)col_ceil_div(n, 256); }
@@ -311,65 +597,103 @@ inline unsigned blocks_for(uint64_t n) { return (unsigned)col_ceil_div(n, 256); 
 
 extern "C" {
 
-int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_scalars, void *out8, int coord_bytes) {
-    if (stride_scalars < 8) return COL_EINVAL;
+size_t col_partition_scratch_bytes(void) { return (size_t)SR_BLOCKS * RG_VALS * sizeof(double); }
+
+static inline unsigned range_blocks(uint32_t n) {
+    const uint64_t b = col_ceil_div(n, 256 * RU);
+    return (unsigned)(b < 1 ? 1 : b > SR_BLOCKS ? SR_BLOCKS : b);
+}
+
+// scratch: col_partition_scratch_bytes() bytes (block partials)
+int col_partition_sample(void *stream, const void *rows, uint32_t n, uint32_t samples, void *payload, void *scratch,
+                         uint32_t *zero, uint32_t zero_count, int coord_bytes) {
+    if (samples == 0 || !scratch || zero_count > 256) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_fold_boxes<float><<<dim3(1), dim3(64), 0, s>>>((const float *)boxes, count, stride_scalars, (float *)out8)),
-                 (k_fold_boxes<double><<<dim3(1), dim3(64), 0, s>>>((const double *)boxes, count, stride_scalars, (double *)out8)));
+    const unsigned g = range_blocks(n), gs = blocks_for(samples);
+    COL_BY_COORD((k_range_part<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, n, (float *)scratch)),
+                 (k_range_part<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, n, (double *)scratch)));
+    COL_LAUNCH_OK();
+    COL_BY_COORD((k_range_fold<float><<<dim3(gs), dim3(256), 0, s>>>((const float4 *)rows, n, samples, (const float *)scratch, g, (float4 *)payload, zero, zero_count)),
+                 (k_range_fold<double><<<dim3(gs), dim3(256), 0, s>>>((const double4 *)rows, n, samples, (const double *)scratch, g, (double4 *)payload, zero, zero_count)));
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows, int coord_bytes) {
-    if (samples == 0) return COL_OK;
+// out = the COL_REGION_BOXES region boxes of rows[0..n) (2 rows of 4 scalars each; see k_region_part); range8 = the
+// global scene range of the repartition, or NULL: one box (octant 0).  Clears zero[0..zero_count).
+int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out, uint32_t *zero,
+                     uint32_t zero_count, int coord_bytes) {
+    if (!scratch || zero_count > 256) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_sample_rows<float><<<dim3(blocks_for(samples)), dim3(256), 0, s>>>((const float4 *)rows, n, samples, (float4 *)out_rows)),
-                 (k_sample_rows<double><<<dim3(blocks_for(samples)), dim3(256), 0, s>>>((const double4 *)rows, n, samples, (double4 *)out_rows)));
+    const unsigned g = range_blocks(n);
+    COL_BY_COORD((k_region_part<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, n, (const float *)range8, (float *)scratch)),
+                 (k_region_part<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, n, (const double *)range8, (double *)scratch)));
+    COL_LAUNCH_OK();
+    COL_BY_COORD((k_region_fold<float><<<dim3(1), dim3(256), 0, s>>>((const float *)scratch, g, (float4 *)out, zero, zero_count)),
+                 (k_region_fold<double><<<dim3(1), dim3(256), 0, s>>>((const double *)scratch, g, (double4 *)out, zero, zero_count)));
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-int col_region_box(void *stream, const void *minmax8, void *out8, int coord_bytes) {
-    hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_region_box<float><<<dim3(1), dim3(64), 0, s>>>((const float *)minmax8, (float *)out8)),
-                 (k_region_box<double><<<dim3(1), dim3(64), 0, s>>>((const double *)minmax8, (double *)out8)));
-    COL_LAUNCH_OK();
-    return COL_OK;
-}
-
-int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out) {
-    if (world < 2) return COL_OK;
-    if (count == 0 || count > SPL_MAX || count < world) return COL_EINVAL;
-    k_splitters<<<dim3(1), dim3(1024), 0, col_stream(stream)>>>(samples, count, world, out);
-    COL_LAUNCH_OK();
-    return COL_OK;
-}
-
-int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
-                     uint32_t *out) {
-    if (world == 0 || world > 256) return COL_EINVAL;
-    k_digit_counts<<<dim3(1), dim3(256), 0, col_stream(stream)>>>(scanned_hist, nblocks, world, n, out);
-    COL_LAUNCH_OK();
-    return COL_OK;
-}
-
-int col_pack_records(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec,
-                     int coord_bytes) {
+// gathered: [world][samples + 2] rows (col_partition_sample of every rank).  Writes the global range (range8),
+// the world - 1 splitters, dest[i] = owner of row i, the scanned owner histogram for col_partition_group
+// (256 * ceil(n / col_radix_tile(n, 4, 4)) words) and owner_counts[0..world).
+int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint32_t samples, const void *rows, uint32_t n,
+                       void *range8, uint32_t *splitters, uint32_t *dest, uint32_t *hist, uint32_t *owner_counts, int coord_bytes) {
+    if (world == 0 || world > 256 || (uint64_t)world * (samples + 2) > SPL_MAX || samples + 2 < world) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
-    if (n == 0) return COL_OK;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_pack_records<float><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const float4 *)rows, gids, idx, n, (u32 *)rec)),
-                 (k_pack_records<double><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const double4 *)rows, gids, idx, n, (u32 *)rec)));
+    COL_BY_COORD((k_splitters<float><<<dim3(1), dim3(1024), 0, s>>>((const float4 *)gathered, world, samples, (float *)range8, splitters)),
+                 (k_splitters<double><<<dim3(1), dim3(1024), 0, s>>>((const double4 *)gathered, world, samples, (double *)range8, splitters)));
+    COL_LAUNCH_OK();
+    if (n == 0) {
+        COL_HIP(hipMemsetAsync(owner_counts, 0, sizeof(u32) * world, s));
+        return COL_OK;
+    }
+    const u32 tile = (u32)col_radix_tile(n, 4, 4);
+    const u32 nb = (u32)col_ceil_div(n, tile);
+    COL_BY_COORD((k_owners<float><<<dim3(nb), dim3(256), 0, s>>>((const float4 *)rows, n, (const float *)range8, splitters, world, tile, nb, dest, hist)),
+                 (k_owners<double><<<dim3(nb), dim3(256), 0, s>>>((const double4 *)rows, n, (const double *)range8, splitters, world, tile, nb, dest, hist)));
+    COL_LAUNCH_OK();
+    k_owner_offsets<<<dim3(1), dim3(1024), 0, s>>>(hist, nb, world, owner_counts);
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-int col_unpack_records(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii, int coord_bytes) {
+// iota: 0, 1, 2, ... (n words); owners_sorted / perm: n words each.  send: (world - 1) slots of (slot + 1)
+// transport records, in rank order without this rank.  flags[2] = max(flags[2], longest list sent).
+int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
+                        const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world, uint32_t rank,
+                        uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows, uint32_t *own_gids,
+                        void *own_radii, uint32_t *flags, int coord_bytes) {
+    if (world == 0 || world > 256 || rank >= world || slot == 0 || !flags) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
-    if (n == 0) return COL_OK;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_unpack_records<float><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const u32 *)rec, n, (float4 *)rows, gids, (float *)radii)),
-                 (k_unpack_records<double><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const u32 *)rec, n, (double4 *)rows, gids, (double *)radii)));
+    if (n) {
+        int rc = col_radix_scatter(stream, dest, owners_sorted, iota, perm, n, 4, 4, 0, hist);
+        if (rc) return rc;
+    }
+    const unsigned g = n ? blocks_for(n) : 1u;          // (an empty rank still writes its slot headers)
+    COL_BY_COORD((k_partition_pack<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, (u32 *)send, (float4 *)own_rows, own_gids, (float *)own_radii, flags)),
+                 (k_partition_pack<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, (u32 *)send, (double4 *)own_rows, own_gids, (double *)own_radii, flags)));
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+// recv: the slots received from the other ranks, laid out as `send` above.  owned (2 device words) and
+// *host_word (host-visible, e.g. col_host_alloc; may be NULL) receive the owned count, see k_partition_unpack.
+int col_partition_unpack(void *stream, const void *recv, uint32_t world, uint32_t rank, uint32_t slot,
+                         const uint32_t *owner_counts, void *own_rows, uint32_t *own_gids, void *own_radii, uint32_t capacity,
+                         uint32_t *owned, void *host_word, uint32_t seq, uint32_t *flags, int coord_bytes) {
+    if (world == 0 || world > 256 || rank >= world || slot == 0 || !flags || !owned) return COL_EINVAL;
+    if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
+    hipStream_t s = col_stream(stream);
+    unsigned gx = blocks_for(slot);
+    if (gx > 512) gx = 512;
+    if (world == 1) gx = 1;
+    dim3 grid(gx, world > 1 ? world - 1 : 1);
+    COL_BY_COORD((k_partition_unpack<float><<<grid, dim3(256), 0, s>>>((const u32 *)recv, world, rank, slot, owner_counts, (float4 *)own_rows, own_gids, (float *)own_radii, capacity, owned, (unsigned long long *)host_word, seq, flags)),
+                 (k_partition_unpack<double><<<grid, dim3(256), 0, s>>>((const u32 *)recv, world, rank, slot, owner_counts, (double4 *)own_rows, own_gids, (double *)own_radii, capacity, owned, (unsigned long long *)host_word, seq, flags)));
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -411,15 +735,6 @@ int col_pack_slots(void *stream, const void *rows, const uint32_t *gids, const u
     hipStream_t s = col_stream(stream);
     COL_BY_COORD((k_pack_slots<float><<<dim3(gx, (unsigned)n_lists), dim3(256), 0, s>>>((const float4 *)rows, gids, lists, stride, counts, (u32 *)rec, slot_records)),
                  (k_pack_slots<double><<<dim3(gx, (unsigned)n_lists), dim3(256), 0, s>>>((const double4 *)rows, gids, lists, stride, counts, (u32 *)rec, slot_records)));
-    COL_LAUNCH_OK();
-    return COL_OK;
-}
-
-int col_bucketize_u32(void *stream, const uint32_t *codes, uint32_t n, const uint32_t *splitters, uint32_t n_split,
-                      uint32_t *dest) {
-    if (n_split > 255) return COL_EINVAL;
-    if (n == 0) return COL_OK;
-    k_bucketize<<<dim3(blocks_for(n)), dim3(256), 0, col_stream(stream)>>>(codes, n, splitters, n_split, dest);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -66,7 +66,7 @@ int col_device_name(char *buf, int len) {
 
 int col_malloc(void **ptr, size_t bytes) { COL_HIP(hipMalloc(ptr, bytes ? bytes : 4)); return COL_OK; }
 int col_free(void *ptr) { COL_HIP(hipFree(ptr)); return COL_OK; }
-int col_host_alloc(void **ptr, size_t bytes) { COL_HIP(hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocDefault)); return COL_OK; }
+int col_host_alloc(void **ptr, size_t bytes) { COL_HIP(hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocCoherent)); return COL_OK; }
 int col_host_free(void *ptr) { COL_HIP(hipHostFree(ptr)); return COL_OK; }
 
 int col_memcpy_h2d(void *stream, void *dst, const void *src, size_t bytes) {

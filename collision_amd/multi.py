@@ -3,31 +3,34 @@
 New work -- the reference is single-device.  Spheres arrive partitioned by
 ``hash(id) mod R`` (BASELINE config 4).  One step on every rank:
 
-1. **AABB all-gather** (one collective): every rank contributes the min/max of its centres and
-   SAMPLES of its spheres.  Folding the boxes gives the global scene range, so Morton codes mean the
-   same thing on every rank; the codes of the gathered samples give the splitters.
-2. **Spatial repartition** (``partition="morton"``, default): Morton code per sphere, R-1 splitters =
-   quantiles of the sample codes (balanced for clustered scenes too), one radix pass that groups the
-   spheres by owner rank, a count all-gather (the step's ONE host sync -- the local pipeline needs the
-   number of owned spheres on the host; the grouping scatter and the packing run meanwhile) and one
-   variable-size all-to-all of transport records ``(x, y, z, r, id)`` (5 words for f32 coordinates, 9 for f64).  Each rank now owns a contiguous
-   Morton range, i.e. a compact region.  With ``partition="hash"`` this step is skipped and every rank
-   keeps its hash subset (its region is then the whole scene).
+1. **AABB all-gather** (one collective, ``partition="morton"``): every rank contributes the min/max of
+   its centres and SAMPLES of its spheres (one launch).  Folding the boxes gives the global scene range, so
+   Morton codes mean the same thing on every rank; the codes of the gathered samples give the splitters.
+2. **Spatial repartition** (``partition="morton"``, default): R-1 splitters = quantiles of the sample codes
+   (balanced for clustered scenes too); owner of every sphere and the per-tile owner histogram (one launch,
+   the codes are never stored), scanned; one radix scatter groups the spheres by owner; one launch packs:
+   what the rank keeps goes STRAIGHT into its owned arrays (it never travels), the rest into one fixed-size
+   SLOT per other rank -- a header record with the list's length, then transport records ``(x, y, z, r, id)``
+   (5 words for f32 coordinates, 9 for f64).  ONE fixed-size all-to-all moves the slots: no count exchange;
+   the host enqueues all of this without waiting for anything.  The unpack launch appends the received
+   spheres to the owned arrays and publishes the owned count in a host-visible word: the step's ONE host
+   wait (the local pipeline's launch sizes depend on it) is a poll of that word.  Each rank now owns a
+   contiguous Morton range, i.e. a compact region.  With ``partition="hash"`` steps 1-2 are skipped and every
+   rank keeps its hash subset (its region is then the whole scene).
 3. Two branches run concurrently from here:
-   a. **Local path** (main stream): exactly the single-GPU pipeline (``col_collide``) on the owned
-      spheres; pair ids are translated from local indices to global ids.
-   b. **Halo exchange** (side stream): the rank's region box -- from a bounds reduction over the owned
+   a. **Local path** (main stream, enqueued first): exactly the single-GPU pipeline (``col_collide``) on the
+      owned spheres; pair ids are translated from local indices to global ids.
+   b. **Halo exchange** (side stream): the rank's region box -- one bounds-reduction launch over the owned
       spheres, NOT from the tree, so it does not wait for 3a -- goes through the second AABB
       all-gather; one launch selects, for every peer that answers for me, the owned spheres whose box
-      overlaps that peer's region, one launch packs them into fixed-size SLOTS (a header record with
-      the count, then the records), and one fixed-size all-to-all moves the slots (direct peer-to-peer
-      over xGMI, no ring).  No count exchange, no host sync: the counts travel in the headers.
+      overlaps that peer's region, one launch packs them into fixed-size slots as above, and one fixed-size
+      all-to-all moves the slots (direct peer-to-peer over xGMI, no ring).
 4. **Ghost queries**: received spheres are QUERIES against the local tree (never inserted) and emit
    ``(ghost id, local id)`` pairs; the kernel reads the slot lengths from the headers.
 
-A slot that is too small for its list is detected from its header (``synchronize`` reads the flag): the
-slot size is then raised on every rank and the step repeated, so results read after ``synchronize`` are
-always exact.  ``synchronize`` also adapts the slot size to 1.5 x the longest list seen.
+A slot (repartition or halo) that is too small for its list is detected from its header (``synchronize``
+reads the flags): the slot size is then raised on every rank and the step repeated, so results read after
+``synchronize`` are always exact.  ``synchronize`` also lets the slot sizes follow the longest lists seen.
 
 A cross-rank pair {a in r, b in q} is reported by exactly one side: rank r answers the ghosts of
 rank q iff ``handles(r, q, R)``.  The union over ranks of the unordered id pairs equals the
@@ -45,6 +48,7 @@ from . import hip
 from ._lib import call
 from .misc import roundUp
 
+REGION_BOXES = 8        # boxes per rank region (one per octant of the scene: COL_REGION_BOXES)
 SAMPLES = 1022          # splitter samples per rank (+ 2 range rows = 1024 rows per rank; 16 ranks fill k_splitters' LDS)
 MAX_PEERS = 8           # halo peers per rank (col_select_overlap_multi): world sizes up to 16
 
@@ -112,12 +116,6 @@ class Exchange:
             work.wait()                       # the current stream waits for the collective (no host sync)
         return out
 
-    def counts_matrix(self, started):
-        """Finish an all-gather of per-destination counts and bring it to the host (the host sync):
-        (send_counts, recv_counts) as Python lists."""
-        mat = self.all_gather_finish(started).cpu()
-        return [int(v) for v in mat[self.rank].tolist()], [int(v) for v in mat[:, self.rank].tolist()]
-
     def all_to_all_v(self, send, send_counts, recv, recv_counts):
         """Rows grouped by destination in `send`, received grouped by source into `recv`; the counts
         (rows per rank) are host lists."""
@@ -145,18 +143,22 @@ class Exchange:
         recv[:nr] = r.to(recv.device)
 
     def all_reduce(self, value, op="sum"):
+        """An int, or a list of ints reduced element-wise in one collective."""
         torch = self.torch
-        t = torch.tensor([value], dtype=torch.int64)
+        many = isinstance(value, (list, tuple))
+        t = torch.tensor(list(value) if many else [value], dtype=torch.int64)
         if self.nccl:
             t = t.to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
-        return int(t.item())
+        out = [int(v) for v in t.cpu().tolist()]
+        return out if many else out[0]
 
 
 # --------------------------------------------------------------------------- device engine
 class ProtocolOps:
-    """The small tensor steps between the collectives, written with tensor-library calls.  HipEngine
-    replaces each of them by ONE launch through the C ABI; the CPU test double keeps these."""
+    """The device steps of the protocol written with tensor-library calls (what the CPU test double runs).
+    HipEngine replaces each of them by one C-ABI call of one to three launches.  An engine provides the
+    buffers (owned_rows, owned_gids, part_send, part_recv, ...), codes_of_rows, pack5 and unpack5."""
 
     def sample_and_range(self, rows, n):
         """[SAMPLES + 2, 4]: SAMPLES evenly strided rows, then the min row and the max row of all n."""
@@ -175,23 +177,82 @@ class ProtocolOps:
         return torch.cat([gathered[:, SAMPLES].min(dim=0).values, gathered[:, SAMPLES + 1].max(dim=0).values]).contiguous()
 
     def splitters_from(self, gathered, grange, world):
-        """world - 1 quantiles of the Morton codes (uint32 order) of all gathered rows, int32 tensor."""
+        """world - 1 quantiles of the Morton codes (uint32 order) of all gathered rows, int64 tensor."""
         torch = self.torch
         codes = self.codes_of_rows(gathered.reshape(-1, 4), grange)
         flat = (codes.to(torch.int64) & 0xFFFFFFFF).sort().values
         cut = torch.arange(1, world, device=flat.device, dtype=torch.int64) * (flat.numel() // world)
-        return flat[cut].to(torch.int32).contiguous()
+        return flat[cut].contiguous()
 
-    def region_box(self, rows, n):
-        """Box of everything this rank owns, conservative: (min centre - max r, max centre + max r)."""
+    def partition_plan(self, gathered, rows, n, world):
+        """Global range, splitters, owner of every row (number of splitters <= its code), rows per owner."""
         torch = self.torch
+        grange = self._grange = self.fold_ranges(gathered)
+        splitters = self.splitters_from(gathered, grange, world)
+        codes = self.codes_of_rows(rows[:n], grange).to(torch.int64) & 0xFFFFFFFF
+        self._dest = torch.searchsorted(splitters, codes, right=True)
+        self._owner_counts = torch.bincount(self._dest, minlength=world)
+
+    def ensure_partition_slots(self, slot, world):
+        """Send / receive buffers of the slotted repartition: (slot + 1) records per other rank."""
+        want = max(1, world - 1) * (slot + 1)
+        if self.part_send is None or self.part_send.shape[0] != want:
+            self.part_send, self.part_recv = self._recs(want), self._recs(want)
+
+    def partition_group(self, rows, gids, n, world, rank, slot):
+        """Stable grouping by owner; kept rows to the front of the owned arrays, the others into their slots."""
+        torch = self.torch
+        perm = torch.sort(self._dest, stable=True).indices
+        starts = [0] + [int(v) for v in torch.cumsum(self._owner_counts, 0).tolist()]
+        for q in range(world):
+            idx = perm[starts[q]:starts[q + 1]]
+            cnt = int(idx.numel())
+            if q == rank:
+                self.owned_rows[:cnt] = rows[idx]
+                self.owned_gids[:cnt] = gids[idx]
+                self._kept = cnt
+                continue
+            base = (q if q < rank else q - 1) * (slot + 1)
+            self.part_send[base] = 0
+            self.part_send[base, 0] = cnt
+            self._longest_part = max(self._longest_part, cnt)
+            self.pack5(rows, gids, idx.to(torch.int32), 0, min(cnt, slot), self.part_send, base + 1)
+
+    def partition_unpack(self, world, rank, slot):
+        """Received slots, in rank order, behind the kept rows; the owned count m."""
+        off = self._kept
+        for k in range(world - 1):
+            base = k * (slot + 1)
+            length = int(self.part_recv[base, 0])
+            self._longest_part = max(self._longest_part, length)
+            cnt = min(length, slot)
+            take = max(0, min(cnt, self.capacity - off))
+            self.unpack5(self.part_recv[base + 1:base + 1 + take], take, self.owned_rows[off:], self.owned_gids[off:])
+            off += cnt
+        self._m = off
+
+    def owned_count(self):
+        return self._m
+
+    def region_boxes(self, rows, n, repartitioned):
+        """[REGION_BOXES, 8]: this rank's region = one conservative box (min centre - max r, 0, max centre + max r,
+        0) per octant of the global scene range over the owned spheres of that octant (an empty octant: an inverted
+        box).  A Morton range is a compact piece inside an octant; one box around a range that spills over an
+        octant boundary by a few spheres would cover a quarter of the scene.  Without a repartition: one box."""
+        torch = self.torch
+        inf = float("inf")
+        out = torch.tensor([inf] * 3 + [0.0] + [-inf] * 3 + [0.0], dtype=rows.dtype, device=rows.device).repeat(REGION_BOXES, 1)
         if n == 0:
-            inf = float("inf")
-            return torch.tensor([inf] * 4 + [-inf] * 4, dtype=rows.dtype, device=rows.device)
-        mn, mx = rows[:n].min(dim=0).values, rows[:n].max(dim=0).values
-        out = torch.cat([mn - mx[3], mx + mx[3]])
-        out[3] = 0
-        out[7] = 0
+            return out
+        r = rows[:n]
+        octant = torch.zeros(n, dtype=torch.int64, device=rows.device)
+        if repartitioned:
+            octant = (self.codes_of_rows(r, self._grange).to(torch.int64) & 0xFFFFFFFF) >> 27
+        for o in range(REGION_BOXES):
+            sel = r[octant == o]
+            if sel.shape[0]:
+                mn, mx = sel.min(dim=0).values, sel.max(dim=0).values
+                out[o, :3], out[o, 4:7] = mn[:3] - mx[3], mx[:3] + mx[3]
         return out.contiguous()
 
 
@@ -227,36 +288,56 @@ class HipEngine(ProtocolOps):
             return torch.zeros(n, dtype=i32, device=dev)
 
         def recs(n):
-            return torch.zeros((n, self.rw), dtype=i32, device=dev)       # transport records (x, y, z, r, gid)
+            # transport records (x, y, z, r, gid).  NOT filled: a fill launch on the allocating stream could land
+            # after the other stream's pack launch; every slot header is written by the pack launches and nothing
+            # behind a list's length is ever read
+            return torch.empty((n, self.rw), dtype=i32, device=dev)
 
         self._recs = recs
         self.rows_in, self.gids_in = rows(capacity), ints(capacity)
-        self.codes, self.codes_sorted, self.iota, self.perm = ints(capacity), ints(capacity), ints(capacity), ints(capacity)
-        self.dest = ints(capacity)
+        self.dest, self.owners_sorted, self.perm = ints(capacity), ints(capacity), ints(capacity)
+        self.iota = torch.arange(capacity, dtype=i32, device=dev)
         nb_max = -(-capacity // call.col_radix_tile(1, 4, 4))            # the small tile bounds the block count
         self.hist = ints(256 * nb_max)
-        self._scan_scratch = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb_max))
-        self.send5, self.recv5 = recs(capacity), recs(capacity)
         self.owned_rows, self.owned_gids = rows(capacity), ints(capacity)
         self.radii = torch.zeros(capacity, dtype=f32, device=dev)
         self.sel_lists, self.sel_counts = ints(MAX_PEERS * capacity), ints(MAX_PEERS)
+        self.part_send = self.part_recv = None
         self.halo_send = self.halo_recv = None
         self.pairs = torch.zeros((pair_capacity, 2), dtype=i32, device=dev)
         self.counter = ints(1)
-        self.flags = ints(2)                                   # [longest slot header seen, ghosts queried]
+        self.flags = ints(4)               # [longest halo header seen, ghosts queried, longest repartition list, -]
+        self.owned2 = ints(2)              # [min(m, capacity), m] of the last repartition
         self.payload = rows(SAMPLES + 2)
-        self.minmax8 = torch.zeros(8, dtype=f32, device=dev)
         self.grange8 = torch.zeros(8, dtype=f32, device=dev)
-        self.box8 = torch.zeros(8, dtype=f32, device=dev)
-        self.sample_codes = ints(16 * (SAMPLES + 2))
+        self.boxes = torch.zeros((REGION_BOXES, 8), dtype=f32, device=dev)
         self.split, self.owner_counts = ints(256), ints(256)
         self.collider = Collider(ctx, capacity, 64, group_size, self.coord_dtype)
         self.collider._allocate()
-        self._tc = 0 if self.cb == 4 else 1                   # COL_F32 / COL_F64
-        self._reduce_scratch = hip.Buffer(ctx, call.col_reduce_scratch_bytes(self._tc, 4))
-        self._reduce_scratch_side = hip.Buffer(ctx, call.col_reduce_scratch_bytes(self._tc, 4))
+        nscratch = call.col_partition_scratch_bytes()
+        self._range_scratch = torch.zeros(nscratch, dtype=torch.uint8, device=dev)        # main stream
+        self._range_scratch_side = torch.zeros(nscratch, dtype=torch.uint8, device=dev)   # halo branch
+        word = C.c_void_p()
+        call.col_host_alloc(C.byref(word), 64)
+        self._host_word = word.value                           # host-visible: (step number << 32 | owned count)
+        C.c_uint64.from_address(self._host_word).value = 0
+        self._seq = 0
+        self._fork_event = torch.cuda.Event()
+        self._owned_event = torch.cuda.Event()
         self.n_owned = 0
-        self._nb = 0
+        # pointers of the persistent buffers (the per-step C calls then convert nothing but a few integers)
+        self._p = {k: getattr(self, k).data_ptr() for k in
+                   ("rows_in", "gids_in", "dest", "owners_sorted", "perm", "iota", "hist", "owned_rows", "owned_gids",
+                    "radii", "sel_lists", "sel_counts", "pairs", "counter", "flags", "owned2", "payload", "grange8",
+                    "boxes", "split", "owner_counts", "_range_scratch", "_range_scratch_side")}
+
+    def __del__(self):
+        word, self._host_word = getattr(self, "_host_word", None), None
+        if word:
+            try:
+                call.col_host_free(word)
+            except Exception:
+                pass
 
     # -- inputs
     def load(self, coords4, radii, gids):
@@ -271,12 +352,17 @@ class HipEngine(ProtocolOps):
         return n
 
     # -- streams
-    def begin_step(self):
-        self.flags.zero_()
+    def begin_step(self, sampled):
+        """Per-step flags are cleared by the sample launch when there is one."""
+        if not sampled:
+            self.flags.zero_()
+
+    def mark_fork(self):
+        """The halo branch may start after everything enqueued on the main stream SO FAR."""
+        self._fork_event.record(self.main)
 
     def fork(self):
-        """The halo branch (side stream) starts after everything enqueued on the main stream so far."""
-        self.side.wait_stream(self.main)
+        self.side.wait_event(self._fork_event)
 
     def halo_stream(self):
         return self.torch.cuda.stream(self.side)
@@ -284,104 +370,69 @@ class HipEngine(ProtocolOps):
     def join(self):
         self.main.wait_stream(self.side)
 
-    # -- steps (all asynchronous, on the main stream unless they belong to the halo branch)
+    # -- repartition (main stream, nothing here waits for the device)
     def sample_and_range(self, rows, n):
-        s = self.cq.stream
-        call.col_sample_rows(s, rows.data_ptr(), n, SAMPLES, self.payload.data_ptr(), self.cb)
-        if n == 0:
-            self.payload[SAMPLES] = float("inf")
-            self.payload[SAMPLES + 1] = float("-inf")
-        else:
-            call.col_reduce(s, rows.data_ptr(), n, self._tc, 4, 0, self._reduce_scratch.ptr,
-                            self.payload.data_ptr() + 4 * self.cb * SAMPLES)
+        p = self._p
+        call.col_partition_sample(self.cq.stream, rows.data_ptr(), n, SAMPLES, p["payload"], p["_range_scratch"],
+                                  p["flags"], 4, self.cb)
         return self.payload
 
-    def fold_ranges(self, gathered):
-        world = int(gathered.shape[0])
-        call.col_fold_boxes_strided(self.cq.stream, gathered.data_ptr() + 4 * self.cb * SAMPLES, world, 4 * (SAMPLES + 2),
-                                    self.grange8.data_ptr(), self.cb)
-        return self.grange8
+    def partition_plan(self, gathered, rows, n, world):
+        p = self._p
+        call.col_partition_plan(self.cq.stream, gathered.data_ptr(), world, SAMPLES, rows.data_ptr(), n, p["grange8"],
+                                p["split"], p["dest"], p["hist"], p["owner_counts"], self.cb)
 
-    def codes_of_rows(self, rows, range8):
-        """Morton codes of (m, 4) gathered sample rows under the range."""
-        m = int(rows.shape[0])
-        if m > self.sample_codes.numel():
-            raise ValueError("more than %d sample rows" % self.sample_codes.numel())
-        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), m, m, self.cb, self.sample_codes.data_ptr(), None)
-        return self.sample_codes[:m]
+    def partition_group(self, rows, gids, n, world, rank, slot):
+        p = self._p
+        call.col_partition_group(self.cq.stream, rows.data_ptr(), gids.data_ptr(), n, p["dest"], p["iota"], p["hist"],
+                                 p["owner_counts"], world, rank, slot, p["owners_sorted"], p["perm"],
+                                 self.part_send.data_ptr(), p["owned_rows"], p["owned_gids"], p["radii"], p["flags"],
+                                 self.cb)
 
-    def splitters_from(self, gathered, grange, world):
-        codes = self.codes_of_rows(gathered.reshape(-1, 4), grange)
-        call.col_splitters_u32(self.cq.stream, codes.data_ptr(), int(codes.numel()), world, self.split.data_ptr())
-        return self.split[:world - 1]
+    def partition_unpack(self, world, rank, slot):
+        p = self._p
+        self._seq = (self._seq % 0xFFFFFFF0) + 1
+        call.col_partition_unpack(self.cq.stream, self.part_recv.data_ptr(), world, rank, slot, p["owner_counts"],
+                                  p["owned_rows"], p["owned_gids"], p["radii"], self.capacity, p["owned2"],
+                                  self._host_word, self._seq, p["flags"], self.cb)
+        self._owned_event.record(self.main)
 
-    def codes_of(self, rows, n, range8):
-        """Morton codes of the local rows under the global scene range (unsorted) + the index ramp."""
-        call.col_morton(self.cq.stream, rows.data_ptr(), range8.data_ptr(), n, n, self.cb, self.codes.data_ptr(),
-                        self.iota.data_ptr())
-        return self.codes
+    def owned_count(self):
+        """The step's one host wait: the unpack launch writes (step number << 32 | m) into a host-visible word."""
+        word, seq, ev = C.c_uint64.from_address(self._host_word), self._seq, self._owned_event
+        spins = 0
+        while (word.value >> 32) != seq:
+            spins += 1
+            if (spins & 255) == 0 and ev.query():              # the launch has completed: its store is visible
+                if (word.value >> 32) != seq:
+                    raise RuntimeError("the repartition did not publish its owned count")
+                break
+        return int(word.value & 0xFFFFFFFF)
 
-    def owner_counts_of(self, codes, n, splitters):
-        """First half of the stable grouping by destination rank -- ONE 8-bit radix pass over the owner
-        index (histogram -> scan of the production sort) instead of a full sort by code: the number of
-        spheres per owner, on the device."""
-        torch, s = self.torch, self.cq.stream
-        world = int(splitters.numel()) + 1
-        if n == 0:
-            return torch.zeros(world, dtype=torch.int32, device=self.device)
-        call.col_bucketize_u32(s, codes.data_ptr(), n, splitters.data_ptr(), world - 1, self.dest.data_ptr())
-        self._nb = nb = -(-n // call.col_radix_tile(n, 4, 4))
-        hist = self.hist[:256 * nb]
-        call.col_radix_histogram(s, self.dest.data_ptr(), n, 4, 4, 0, hist.data_ptr())
-        call.col_scan_u32(s, hist.data_ptr(), 256 * nb, self._scan_scratch.ptr)
-        call.col_digit_counts(s, hist.data_ptr(), nb, world, n, self.owner_counts.data_ptr())
-        return self.owner_counts[:world]
-
-    def finish_grouping(self, n):
-        """Second half: the scatter; perm lists the spheres owner by owner."""
-        if n:
-            call.col_radix_scatter(self.cq.stream, self.dest.data_ptr(), self.codes_sorted.data_ptr(), self.iota.data_ptr(),
-                                   self.perm.data_ptr(), n, 4, 4, 0, self.hist.data_ptr())
-        return self.perm
-
-    def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
-        """out5[out_offset + i] = (rows[idx[idx_offset + i]], gids[...]) for i < n (idx None = identity)."""
-        call.col_pack_records(self.cq.stream, rows.data_ptr(), gids.data_ptr(),
-                              None if idx is None else idx.data_ptr() + 4 * idx_offset, n,
-                              out5.data_ptr() + 4 * self.rw * out_offset, self.cb)
-
-    def unpack5(self, rec5, n, rows, gids, radii=None):
-        call.col_unpack_records(self.cq.stream, rec5.data_ptr(), n, rows.data_ptr(), gids.data_ptr(),
-                                None if radii is None else radii.data_ptr(), self.cb)
-
+    # -- local path (main stream)
     def collide(self, rows, gids, n):
-        """Single-GPU path on the owned spheres (main stream); pairs come out as global ids."""
+        """Single-GPU path on the owned spheres; pairs come out as global ids."""
         s = self.cq.stream
         self.n_owned = n
         if n == 0:
             self.counter.zero_()
             return                                # (col_collide zeroes the counter itself)
-        c = self.collider
-        if rows is not self.owned_rows:           # owned rows come out of unpack5 with radii already split off
-            call.col_unpack_radii(s, rows.data_ptr(), n, self.radii.data_ptr(), self.cb)
-        call.col_collide_plan(s, rows.data_ptr(), self.radii.data_ptr(), n, roundUp(n, 2 * self.group_size), self.cb,
+        c, p = self.collider, self._p
+        if rows is not self.owned_rows:           # owned rows come out of the repartition with radii already split off
+            call.col_unpack_radii(s, rows.data_ptr(), n, p["radii"], self.cb)
+        call.col_collide_plan(s, rows.data_ptr(), p["radii"], n, roundUp(n, 2 * self.group_size), self.cb,
                               c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
                               c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
-                              self.counter.data_ptr(), self.pairs.data_ptr(), self.pair_capacity,
-                              c._choose_sort_plan(), c._plan_word)
-        call.col_translate_pairs(s, self.pairs.data_ptr(), self.counter.data_ptr(), 0, self.pair_capacity,
-                                 gids.data_ptr())
+                              p["counter"], p["pairs"], self.pair_capacity, c._choose_sort_plan(), c._plan_word)
+        call.col_translate_pairs(s, p["pairs"], p["counter"], 0, self.pair_capacity, gids.data_ptr())
 
     # -- halo branch (side stream)
-    def region_box(self, rows, n):
-        s = self.cq_side.stream
-        if n == 0:
-            self.box8[:4] = float("inf")
-            self.box8[4:] = float("-inf")
-        else:
-            call.col_reduce(s, rows.data_ptr(), n, self._tc, 4, 0, self._reduce_scratch_side.ptr, self.minmax8.data_ptr())
-            call.col_region_box(s, self.minmax8.data_ptr(), self.box8.data_ptr(), self.cb)
-        return self.box8
+    def region_boxes(self, rows, n, repartitioned):
+        """One launch; also clears the halo list counters."""
+        p = self._p
+        call.col_region_boxes(self.cq_side.stream, rows.data_ptr(), n, p["grange8"] if repartitioned else None,
+                              p["_range_scratch_side"], p["boxes"], p["sel_counts"], MAX_PEERS, self.cb)
+        return self.boxes
 
     def ensure_slots(self, slot, n_out, n_in):
         """Send / receive buffers of the slotted halo exchange: (slot + 1) records per peer."""
@@ -392,33 +443,32 @@ class HipEngine(ProtocolOps):
             self.halo_recv = self._recs(want_r)
 
     def select_and_pack(self, rows, gids, n, boxes_dev, peers, slot):
-        """Halo lists for up to 8 peers in one launch (boxes_dev = the gathered [world, 8] region boxes, on
+        """Halo lists for up to 8 peers in one launch (boxes_dev = the gathered [world, 8, 8] region boxes, on
         the device), packed into one slot per peer by a second launch.  No sync: counts stay on the device."""
-        s = self.cq_side.stream
-        self.sel_counts.zero_()
         if not peers:
             return
+        s, p = self.cq_side.stream, self._p
         arr = (C.c_int * len(peers))(*peers)
         call.col_select_overlap_multi(s, rows.data_ptr(), n, boxes_dev.data_ptr(), arr, len(peers),
-                                      self.capacity, self.sel_lists.data_ptr(), self.sel_counts.data_ptr(), self.cb)
-        call.col_pack_slots(s, rows.data_ptr(), gids.data_ptr(), self.sel_lists.data_ptr(), self.capacity,
-                            self.sel_counts.data_ptr(), len(peers), min(max(n, 1), slot), self.halo_send.data_ptr(),
+                                      self.capacity, p["sel_lists"], p["sel_counts"], self.cb)
+        call.col_pack_slots(s, rows.data_ptr(), gids.data_ptr(), p["sel_lists"], self.capacity,
+                            p["sel_counts"], len(peers), min(max(n, 1), slot), self.halo_send.data_ptr(),
                             int(self.halo_send.shape[0]), slot, self.cb)
 
     def ghost_queries(self, n_in, slot, owned_gids):
         if self.n_owned == 0 or n_in == 0:
             return
+        p = self._p
         call.col_traverse_ghost_slots(self.cq.stream, self.halo_recv.data_ptr(), n_in, slot,
                                       self.collider._bounds_buf.ptr, self.n_owned, owned_gids.data_ptr(),
-                                      self.pairs.data_ptr(), self.counter.data_ptr(), self.pair_capacity,
-                                      self.flags.data_ptr(), self.cb)
+                                      p["pairs"], p["counter"], self.pair_capacity, p["flags"], self.cb)
 
     # -- results (these synchronise)
     def halo_stats(self):
-        """(longest halo list of this rank, sent or received; ghosts queried).  Host sync."""
+        """(longest halo list of this rank, sent or received; ghosts queried; longest repartition list).  Host sync."""
         f = self.flags.cpu().numpy().view(np.uint32)
         sent = int(self.sel_counts.cpu().numpy().view(np.uint32).max())
-        return max(int(f[0]), sent), int(f[1])
+        return max(int(f[0]), sent), int(f[1]), int(f[2])
 
     def pair_count(self):
         return int(self.counter.item()) & 0xFFFFFFFF
@@ -435,7 +485,8 @@ class HipEngine(ProtocolOps):
 # --------------------------------------------------------------------------- the protocol
 class DistributedCollider:
     def __init__(self, ctx, dist, n_local, group_size=256, pair_capacity=1 << 19, partition="morton",
-                 slack=1.6, engine=None, exercise_single_rank=False, halo_slot=None, coord_dtype=np.dtype("float32")):
+                 slack=1.6, engine=None, exercise_single_rank=False, halo_slot=None, coord_dtype=np.dtype("float32"),
+                 partition_slot=None):
         if partition not in ("morton", "hash"):
             raise ValueError("partition must be 'morton' or 'hash'")
         self.dist, self.partition = dist, partition
@@ -451,6 +502,9 @@ class DistributedCollider:
         # one-GPU box drive the real RCCL code paths
         self.exercise = exercise_single_rank
         r, R = self.rank, self.world
+        if partition == "morton" and R * (SAMPLES + 2) > 16384:
+            raise NotImplementedError("the Morton repartition gathers %d sample rows per rank: at most %d ranks"
+                                      % (SAMPLES + 2, 16384 // (SAMPLES + 2)))
         self.peers_out = [q for q in range(R) if handles(q, r, R)]      # they answer for me: my halo goes there
         self.peers_in = [q for q in range(R) if handles(r, q, R)]       # I answer for them: their halo comes here
         if max(len(self.peers_out), len(self.peers_in)) > MAX_PEERS:
@@ -460,6 +514,12 @@ class DistributedCollider:
         self.slot = capacity if partition == "hash" else max(4096, roundUp(capacity // 6, 1024))
         if halo_slot is not None:
             self.slot = int(halo_slot)           # (tests: start too small and let synchronize() repair it)
+        # records per repartition slot (one per other rank): spheres that arrive hash-partitioned leave for every
+        # rank in equal shares; synchronize() follows the longest list seen (a spatially coherent arrival
+        # sends little, and what a rank keeps does not travel at all)
+        self.part_slot = max(1024, roundUp(int(1.3 * n_local / R) + 1024, 1024)) if R > 1 else 1024
+        if partition_slot is not None:
+            self.part_slot = int(partition_slot)
         self.repeats = 0                         # steps repeated because a slot overflowed
         self._dirty = False
 
@@ -471,74 +531,80 @@ class DistributedCollider:
         e, x, R, r = self.engine, self.x, self.world, self.rank
         rows, gids, n = e.rows_in, e.gids_in, self.n_in
         self._dirty = True
-        e.begin_step()
+        several = R > 1 or self.exercise
+        repartition = self.partition == "morton" and several
+        e.begin_step(repartition)
 
-        # 1. ONE all-gather: every rank's centre range and sample rows -> global scene range, splitters
-        gathered = x.all_gather(e.sample_and_range(rows, n))           # [R, SAMPLES + 2, 4]
-        grange = e.fold_ranges(gathered)
-
-        # 2. spatial repartition
-        if self.partition == "morton" and (R > 1 or self.exercise):
-            splitters = e.splitters_from(gathered, grange, R)
-            codes = e.codes_of(rows, n, grange)
-            counts = e.owner_counts_of(codes, n, splitters)
-            started = x.all_gather_start(counts)
-            perm = e.finish_grouping(n)                                # these two overlap the count exchange ...
-            e.pack5(rows, gids, perm, 0, n, e.send5)
-            send_counts, recv_counts = x.counts_matrix(started)        # ... and the step's one host sync
-            m = sum(recv_counts)
+        if repartition:
+            # 1. ONE all-gather: every rank's centre range and sample rows -> global scene range, splitters
+            gathered = x.all_gather(e.sample_and_range(rows, n))       # [R, SAMPLES + 2, 4]
+            # 2. spatial repartition: fixed-size slots, nothing here waits for the device
+            pslot = self.part_slot
+            e.ensure_partition_slots(pslot, R)
+            e.partition_plan(gathered, rows, n, R)
+            e.partition_group(rows, gids, n, R, r, pslot)
+            split = [pslot + 1 if q != r else 0 for q in range(R)]
+            x.all_to_all_v(e.part_send, split, e.part_recv, split)
+            e.partition_unpack(R, r, pslot)
+            e.mark_fork()
+            own_rows, own_gids = e.owned_rows, e.owned_gids
+            m = e.owned_count()                                        # the step's one host wait
             if m > self.capacity:
                 raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
-            x.all_to_all_v(e.send5, send_counts, e.recv5, recv_counts)
-            e.unpack5(e.recv5, m, e.owned_rows, e.owned_gids, e.radii)
-            own_rows, own_gids = e.owned_rows, e.owned_gids
         else:
+            e.mark_fork()
             own_rows, own_gids, m = rows, gids, n
         self.stats["owned"] = m
         self.own_rows, self.own_gids, self.n_owned = own_rows, own_gids, m      # (tests read these back)
 
-        halo = R > 1 or self.exercise
-        if halo:
-            # 3b. halo branch on the side stream, concurrent with the local pipeline below
+        # 3a. the single-GPU path on the owned spheres, enqueued first: the device works on it while the host
+        #     enqueues the halo branch
+        e.collide(own_rows, own_gids, m)
+
+        if several:
+            # 3b. halo branch on the side stream, concurrent with the local pipeline
             slot = self.slot
             e.ensure_slots(slot, len(self.peers_out), len(self.peers_in))
             e.fork()
             with e.halo_stream():
-                boxes = x.all_gather(e.region_box(own_rows, m))        # [R, 8], stays on the device
+                boxes = x.all_gather(e.region_boxes(own_rows, m, repartition))   # [R, 8 boxes, 8], stays on the device
                 e.select_and_pack(own_rows, own_gids, m, boxes, self.peers_out, slot)
                 out_rows = [slot + 1 if q in self.peers_out else 0 for q in range(R)]
                 in_rows = [slot + 1 if q in self.peers_in else 0 for q in range(R)]
                 x.all_to_all_v(e.halo_send, out_rows, e.halo_recv, in_rows)
-
-        # 3a. the single-GPU path on the owned spheres
-        e.collide(own_rows, own_gids, m)
-
-        if halo:
             # 4. ghosts as queries against my tree (slot lengths are read from the headers on the device)
             e.join()
             e.ghost_queries(len(self.peers_in), slot, own_gids)
 
     # -- results -------------------------------------------------------------------------------
     def synchronize(self):
-        """Wait for the enqueued steps.  If a halo slot overflowed in the last step (seen in its header),
-        every rank raises the slot size and the step is repeated, so what is read afterwards is exact;
-        otherwise the slot size follows 1.5 x the longest list any rank has seen."""
+        """Wait for the enqueued steps.  If a slot (repartition or halo) overflowed in the last step (seen in
+        its header), every rank raises that slot size and the step is repeated, so what is read afterwards is
+        exact; otherwise the slot sizes follow the longest lists any rank has seen."""
         e = self.engine
         e.synchronize()
         if not self._dirty or not (self.world > 1 or self.exercise):
             self._dirty = False
             return
+        cap = roundUp(self.capacity, 1024)
         while True:
-            longest, ghosts = e.halo_stats()
-            longest = self.x.all_reduce(longest, "max")
+            longest, ghosts, longest_part = e.halo_stats()
+            longest, longest_part = self.x.all_reduce([longest, longest_part], "max")
             self.stats["ghosts"] = ghosts
-            self.stats["halo_slot"] = self.slot
+            self.stats["halo_slot"], self.stats["partition_slot"] = self.slot, self.part_slot
             want = max(4096, roundUp(longest + longest // 2 + 1024, 1024))
-            if longest <= self.slot:
-                if self.partition != "hash" and (want < self.slot // 2 or want > self.slot):
-                    self.slot = min(want, roundUp(self.capacity, 1024))
+            want_p = max(1024, roundUp(longest_part + longest_part // 4 + 1024, 1024))
+            again = False
+            if longest_part > self.part_slot:
+                self.part_slot, again = min(want_p, cap), True
+            elif want_p < self.part_slot // 2:
+                self.part_slot = want_p
+            if longest > self.slot:
+                self.slot, again = min(want, cap), True
+            elif self.partition != "hash" and (want < self.slot // 2 or want > self.slot):
+                self.slot = min(want, cap)
+            if not again:
                 break
-            self.slot = min(want, roundUp(self.capacity, 1024))
             self.repeats += 1
             self.step()
             e.synchronize()

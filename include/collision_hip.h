@@ -234,31 +234,49 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
  * repartition / halo exchange / ghost queries driven by collision_amd/multi.py over RCCL.
  * coord_bytes 4 | 8.  Rows are 4 scalars (x, y, z, r); a transport record is those 4 scalars
  * followed by the 32-bit global id: 5 words (f32) or 9 words (f64). */
-/* out_rows[i] = rows[i * (n - 1) / (samples - 1)]: a rank's contribution to the splitter sample (n == 0: rows at +inf) */
-int col_sample_rows(void *stream, const void *rows, uint32_t n, uint32_t samples, void *out_rows, int coord_bytes);
-/* out8 = [min of the min rows, max of the max rows] of `count` gathered boxes, `stride_scalars` apart
- * (the tail of each rank's block of the first all-gather) */
-int col_fold_boxes_strided(void *stream, const void *boxes, uint32_t count, uint32_t stride_scalars, void *out8,
-                           int coord_bytes);
-/* world - 1 quantiles of `count` <= 16384 gathered sample codes (sorted on the device) */
-int col_splitters_u32(void *stream, const uint32_t *samples, uint32_t count, uint32_t world, uint32_t *out);
-/* dest[i] = number of (sorted, device) splitters <= codes[i]: the owner rank of a Morton code */
-int col_bucketize_u32(void *stream, const uint32_t *codes, uint32_t n, const uint32_t *splitters,
-                      uint32_t n_split, uint32_t *dest);
-/* elements per digit from the scanned digit-major histogram of a radix pass over the owner index */
-int col_digit_counts(void *stream, const uint32_t *scanned_hist, uint32_t nblocks, uint32_t world, uint32_t n,
-                     uint32_t *out);
-/* transport records: rec[i] = (rows[idx[i]], gids[idx[i]]) (idx NULL = identity) and back */
-int col_pack_records(void *stream, const void *rows, const uint32_t *gids, const uint32_t *idx, uint32_t n, void *rec,
-                     int coord_bytes);
-int col_unpack_records(void *stream, const void *rec, uint32_t n, void *rows, uint32_t *gids, void *radii,
+/* -- the repartition into Morton ranges of equal population: four calls between the collectives --
+ * col_partition_sample (2 launches): payload = `samples` evenly strided rows of rows[0..n) (n == 0: rows at +inf),
+ * then the min row and the max row of all n: what a rank contributes to the first all-gather.  scratch:
+ * col_partition_scratch_bytes() bytes (block partials).  Also clears zero[0 .. zero_count) (zero_count <= 256;
+ * the step's flag words). */
+size_t col_partition_scratch_bytes(void);
+int col_partition_sample(void *stream, const void *rows, uint32_t n, uint32_t samples, void *payload, void *scratch,
+                         uint32_t *zero, uint32_t zero_count, int coord_bytes);
+/* col_partition_plan (3 launches): gathered = [world][samples + 2] rows (every rank's payload; at most 16384 rows).
+ * range8 = the global scene range; splitters = the world - 1 quantiles of the gathered rows' Morton codes;
+ * dest[i] = owner of row i (number of splitters <= its code); hist (256 * ceil(n / col_radix_tile(n, 4, 4)) words)
+ * = the scanned owner histogram col_partition_group needs; owner_counts[q] = rows of owner q. */
+int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint32_t samples, const void *rows, uint32_t n,
+                       void *range8, uint32_t *splitters, uint32_t *dest, uint32_t *hist, uint32_t *owner_counts,
                        int coord_bytes);
+/* col_partition_group (2 launches): stable grouping by owner (one radix scatter of (dest, iota) into
+ * (owners_sorted, perm); iota = 0, 1, 2, ...), then packing: the rows this rank keeps go to the front of
+ * own_rows / own_gids / own_radii; the others into `send`: one SLOT of 1 + slot transport records per other rank
+ * (rank order) -- a header record whose first word is the full length of the list, then min(length, slot)
+ * records.  flags[2] = max(flags[2], longest list). */
+int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
+                        const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world,
+                        uint32_t rank, uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows,
+                        uint32_t *own_gids, void *own_radii, uint32_t *flags, int coord_bytes);
+/* col_partition_unpack (1 launch): recv = the slots received from the other ranks (laid out as `send`) appended to
+ * the owned arrays behind the owner_counts[rank] rows the rank kept.  owned[0] = min(m, capacity), owned[1] = m
+ * (device words), *host_word (host-visible 64-bit word, e.g. col_host_alloc; may be NULL) = seq << 32 | m: the
+ * host waits for that word only, then sizes the local pipeline.  flags[2] = max(flags[2], longest header). */
+int col_partition_unpack(void *stream, const void *recv, uint32_t world, uint32_t rank, uint32_t slot,
+                         const uint32_t *owner_counts, void *own_rows, uint32_t *own_gids, void *own_radii,
+                         uint32_t capacity, uint32_t *owned, void *host_word, uint32_t seq, uint32_t *flags,
+                         int coord_bytes);
 int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii, int coord_bytes);
-/* [min row, max row] of (x, y, z, r) rows (col_reduce, MINMAX, width 4) -> box (min centre - max r, max centre + max r) */
-int col_region_box(void *stream, const void *minmax8, void *out8, int coord_bytes);
-/* halo selection in one launch: boxes = DEVICE array [world][8] (lo.xyz,-,hi.xyz,-) as produced by
- * the AABB all-gather; peers = HOST array of n_peers <= 8 rank numbers; lists[k*stride ...] and
- * counts[k] (zeroed by the caller) receive the spheres overlapping boxes[peers[k]] */
+/* A rank's REGION for the halo selection: 8 boxes, one per octant of the global scene range (range8, from
+ * col_partition_plan; NULL = no repartition: one box, the other seven inverted), each (min centre - max r, 0,
+ * max centre + max r, 0) over the spheres of rows[0..n) in that octant (conservative; an empty octant: an inverted
+ * box nothing overlaps).  out = 8 x 2 rows of 4 scalars.  Two launches; scratch as for col_partition_sample (its own
+ * buffer when the two run on different streams); also clears zero[0 .. zero_count) (the halo list counters). */
+int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out,
+                     uint32_t *zero, uint32_t zero_count, int coord_bytes);
+/* halo selection in one launch: boxes = DEVICE array [world][8 boxes][8] (lo.xyz,-,hi.xyz,-) as produced by
+ * the AABB all-gather of every rank's col_region_boxes; peers = HOST array of n_peers <= 8 rank numbers; lists[k*stride ...] and
+ * counts[k] (zeroed beforehand: col_region_boxes does it) receive the spheres overlapping any box of peers[k] */
 int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
                              int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes);
 /* the n_lists lists as fixed SLOTS of 1 + slot_records records each: a header record (first word = the list's

@@ -39,16 +39,14 @@ class OracleEngine(_protocol_ops()):
         self._wf = self.coord_dtype.itemsize // 4                      # int32 words per scalar
         z4 = lambda n: torch.zeros((n, 4), dtype=self._f)
         zi = lambda n: torch.zeros(n, dtype=torch.int32)
-        self._z5 = lambda n: torch.zeros((n, 4 * self._wf + 1), dtype=torch.int32)
+        self._z5 = self._recs = lambda n: torch.zeros((n, 4 * self._wf + 1), dtype=torch.int32)
         self.rows_in, self.gids_in = z4(capacity), zi(capacity)
-        self.send5, self.recv5 = self._z5(capacity), self._z5(capacity)
         self.owned_rows, self.owned_gids = z4(capacity), zi(capacity)
-        self.radii = torch.zeros(capacity, dtype=self._f)
+        self.part_send = self.part_recv = None
         self.halo_send = self.halo_recv = None
-        self.perm = zi(capacity)
         self.found = []
         self.n_owned = 0
-        self._longest = self._ghosts = 0
+        self._longest = self._ghosts = self._longest_part = self._kept = self._m = 0
 
     def load(self, coords4, radii, gids):
         n = len(coords4)
@@ -58,8 +56,11 @@ class OracleEngine(_protocol_ops()):
         self.gids_in[:n] = self.torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32))
         return n
 
-    def begin_step(self):
-        self._longest = self._ghosts = 0
+    def begin_step(self, sampled):
+        self._longest = self._ghosts = self._longest_part = 0
+
+    def mark_fork(self):
+        pass
 
     def fork(self):
         pass
@@ -73,22 +74,6 @@ class OracleEngine(_protocol_ops()):
     def codes_of_rows(self, rows, range8):
         codes = self.oracle.morton(rows.numpy().copy(), range8.numpy().reshape(2, 4))
         return self.torch.from_numpy(codes.view(np.int32).copy())
-
-    def codes_of(self, rows, n, range8):
-        self.codes = self.torch.zeros(self.capacity, dtype=self.torch.int32)
-        self.codes[:n] = self.codes_of_rows(rows[:n], range8)
-        return self.codes
-
-    def owner_counts_of(self, codes, n, splitters):
-        c = codes[:n].numpy().view(np.uint32)
-        sp = splitters.numpy().view(np.uint32)
-        self._dest = np.searchsorted(sp, c, side="right")
-        return self.torch.from_numpy(np.bincount(self._dest, minlength=len(sp) + 1).astype(np.int32))
-
-    def finish_grouping(self, n):
-        perm = np.argsort(self._dest, kind="stable")
-        self.perm[:n] = self.torch.from_numpy(perm.astype(np.int32))
-        return self.perm
 
     def pack5(self, rows, gids, idx, idx_offset, n, out5, out_offset=0):
         t = self.torch
@@ -128,8 +113,9 @@ class OracleEngine(_protocol_ops()):
         r = rows[:n].numpy()
         lo, hi = r[:, :3] - r[:, 3:4], r[:, :3] + r[:, 3:4]
         for k, q in enumerate(peers):
-            b = boxes[q]
-            hit = ((hi > b[0:3]) & (lo < b[4:7])).all(axis=1) if n else np.zeros(0, bool)
+            hit = np.zeros(n, bool)
+            for b in boxes[q]:                  # a region is several boxes
+                hit |= ((hi > b[0:3]) & (lo < b[4:7])).all(axis=1)
             idx = t.from_numpy(np.nonzero(hit)[0].astype(np.int32))
             self._longest = max(self._longest, len(idx))
             base = k * (slot + 1)
@@ -156,7 +142,7 @@ class OracleEngine(_protocol_ops()):
                 self.found += [(int(gg[i]), int(self._gids[j])) for j in np.nonzero(hit)[0]]
 
     def halo_stats(self):
-        return self._longest, self._ghosts
+        return self._longest, self._ghosts, self._longest_part
 
     def pair_count(self):
         return len(self.found)
@@ -224,6 +210,7 @@ def main():
     mode, partition, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
     halo_slot = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
+    part_slot = int(sys.argv[8]) if len(sys.argv) > 8 and int(sys.argv[8]) > 0 else None
     coord_dtype = np.dtype(sys.argv[7]) if len(sys.argv) > 7 else np.dtype("float32")
     import torch  # noqa: F401
     import torch.distributed as dist
@@ -243,7 +230,8 @@ def main():
         cap = roundUp(int(int(mine.sum()) * 3.0) + 4096, 2 * 64)     # as DistributedCollider sizes it (slack 3)
         engine = OracleEngine(cap, 1 << 20, coord_dtype)
     dc = DistributedCollider(ctx, dist, int(mine.sum()), group_size=64, pair_capacity=1 << 22, partition=partition,
-                             slack=3.0, engine=engine, halo_slot=halo_slot, coord_dtype=coord_dtype)
+                             slack=3.0, engine=engine, halo_slot=halo_slot, coord_dtype=coord_dtype,
+                             partition_slot=part_slot)
     dc.set_local_spheres(coords[mine], radii[mine], gids[mine])
     for _ in range(2):                       # twice: buffers are reused across steps
         dc.step()

@@ -36,12 +36,12 @@ def test_hash_owner_is_balanced():
     assert counts.min() > 0.9 * (1 << 13) and counts.max() < 1.1 * (1 << 13)
 
 
-def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32"):
+def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32", part_slot=0):
     out = tmp_path / ("result_%s_%s_%d.json" % (mode, partition, world))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"),
-           mode, partition, str(n), str(out), kind, str(halo_slot), dtype]
+           mode, partition, str(n), str(out), kind, str(halo_slot), dtype, str(part_slot)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     return json.loads(out.read_text())
@@ -68,6 +68,15 @@ def test_halo_slot_overflow_is_repaired(tmp_path):
     res = _run(3, "cpu", "morton", 1500, tmp_path, "uniform", port=29641, halo_slot=8)
     assert res["ok"], res
     assert all(s["repeats"] >= 1 and s["halo_slot"] >= 4096 for s in res["stats"])
+
+
+def test_partition_slot_overflow_is_repaired(tmp_path):
+    """The repartition travels in fixed-size slots too (one per other rank, the list length in the header, what a
+    rank keeps does not travel).  Slots that start too small truncate the lists; synchronize() sees the headers,
+    every rank grows the slot and the step is repeated."""
+    res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29643, part_slot=16)
+    assert res["ok"], res
+    assert all(s["repeats"] >= 1 and s["partition_slot"] > 16 for s in res["stats"])
 
 
 @pytest.mark.parametrize("partition,kind", [("hash", "uniform"), ("morton", "uniform"), ("morton", "clustered")])
@@ -111,6 +120,13 @@ def test_halo_slot_overflow_is_repaired_on_the_gpu(tmp_path):
     res = _run(3, "gpu", "morton", 30000, tmp_path, "clustered", port=29646, halo_slot=64)
     assert res["ok"], res
     assert all(s["repeats"] >= 1 for s in res["stats"])
+
+
+@pytest.mark.gpu
+def test_partition_slot_overflow_is_repaired_on_the_gpu(tmp_path):
+    res = _run(3, "gpu", "morton", 30000, tmp_path, "uniform", port=29647, part_slot=256)
+    assert res["ok"], res
+    assert all(s["repeats"] >= 1 and s["rank_parity"] == "ok" for s in res["stats"])
 
 
 @pytest.mark.gpu

@@ -13,7 +13,10 @@ from collision_amd.multi import DistributedCollider
 import bench
 n = 1000000
 coords, radii = bench.uniform_scene(n)
-for partition, exercise in (("morton", False), ("morton", True), ("hash", True)):
+configs = (("morton", False), ("morton", True), ("hash", True))
+if len(sys.argv) > 1:
+    configs = ((sys.argv[1], True),)
+for partition, exercise in configs:
     dc = DistributedCollider(hip.Context(0), dist, n, pair_capacity=1 << 19, partition=partition, exercise_single_rank=exercise)
     dc.set_local_spheres(coords, radii, np.arange(n, dtype=np.uint32))
     for _ in range(5):
