@@ -390,19 +390,24 @@ __global__ __launch_bounds__(256) void k_region_fold(const T *__restrict__ parti
     }
 }
 
-// One block: the global scene range (fold of every rank's [min row, max row]) -> range8; the Morton codes
-// of ALL gathered rows (world x (samples + 2), at most SPL_MAX) under that range, sorted in LDS (bitonic);
-// splitter q = the code at position q * count / world.
-constexpr u32 SPL_MAX = 16384;
+// One block: the global scene range (fold of every rank's [min row, max row]) -> range8; the Morton codes of ALL
+// gathered rows (world x (samples + 2), at most SPL_MAX) under that range stay in registers; splitter q = the code
+// of rank q * (count / world) among them, found WITHOUT sorting: a radix select on the 30 code bits, 8 bits per
+// level, one wave per splitter -- per level an LDS histogram of the codes that share the splitter's prefix, then
+// the wave finds the bin its rank falls into.  (A bitonic sort of the codes in LDS took 16 us for one rank's 1024
+// codes and 91 barrier stages for eight ranks' 8192; this is 12 barriers whatever the world size.)
+constexpr u32 SPL_MAX = 16384, SPL_PER = SPL_MAX / 1024, SPL_Q = 15;
 template <typename T>
 __global__ __launch_bounds__(1024) void k_splitters(const typename MT<T>::V4 *__restrict__ gathered, u32 world, u32 samples,
                                                      T *__restrict__ range8, u32 *__restrict__ splitters) {
     typedef typename MT<T>::V4 V4;
-    __shared__ u32 s[SPL_MAX];
+    __shared__ u32 s_hist[SPL_Q][256];
+    __shared__ u32 s_prefix[SPL_Q], s_rank[SPL_Q];
     __shared__ T s_range[8];
-    const u32 per = samples + 2, count = world * per;
-    if (threadIdx.x < 8) {
-        const u32 k = threadIdx.x;
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
+    const u32 per = samples + 2, count = world * per, nq = world - 1;
+    if (tid < 8) {
+        const u32 k = tid;
         T acc = k < 4 ? (T)INFINITY : -(T)INFINITY;
         for (u32 q = 0; q < world; q++) {
             const T v = reinterpret_cast<const T *>(gathered + (u64)q * per + samples + (k >> 2))[k & 3];
@@ -411,33 +416,58 @@ __global__ __launch_bounds__(1024) void k_splitters(const typename MT<T>::V4 *__
         s_range[k] = acc;
         range8[k] = acc;
     }
+    if (tid < nq) { s_prefix[tid] = 0; s_rank[tid] = (tid + 1) * (count / world); }
     __syncthreads();
-    u32 m = 1;
-    while (m < count) m <<= 1;
-    for (u32 i = threadIdx.x; i < m; i += 1024) {
-        u32 code = 0xFFFFFFFFu;
+    u32 code[SPL_PER];
+#pragma unroll
+    for (int j = 0; j < (int)SPL_PER; j++) {
+        const u32 i = tid + 1024u * j;
+        code[j] = 0xFFFFFFFFu;                   // (not a 30-bit code: matches no prefix, counted nowhere)
         if (i < count) {
             const V4 c = gathered[i];
-            code = morton30<T>(c.x, c.y, c.z, s_range[0], s_range[1], s_range[2], s_range[4], s_range[5], s_range[6]);
+            code[j] = morton30<T>(c.x, c.y, c.z, s_range[0], s_range[1], s_range[2], s_range[4], s_range[5], s_range[6]);
         }
-        s[i] = code;
     }
-    __syncthreads();
-    for (u32 k = 2; k <= m; k <<= 1) {
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = threadIdx.x; i < m; i += 1024) {
-                const u32 l = i ^ j;
-                if (l > i) {
-                    const u32 a = s[i], b = s[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[l] = a; }
-                }
+    // levels: code bits [29:22], [21:14], [13:6], [5:0]
+    for (int level = 0; level < 4; level++) {
+        const int shift = level < 3 ? 22 - 8 * level : 0, hi = shift + (level < 3 ? 8 : 6);      // prefix = code >> hi
+        const u32 mask = level < 3 ? 255u : 63u;
+        const u32 nh = level == 0 ? 1u : nq;         // (level 0: every splitter has the empty prefix, one histogram)
+        for (u32 i = tid; i < nh * 256; i += 1024) (&s_hist[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (int)SPL_PER; j++) {
+            const u32 c = code[j];
+            if (c == 0xFFFFFFFFu) continue;
+            if (level == 0) atomicAdd(&s_hist[0][c >> 22], 1u);
+            else
+                for (u32 t = 0; t < nq; t++)
+                    if ((c >> hi) == s_prefix[t]) atomicAdd(&s_hist[t][(c >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        u32 new_prefix = 0, new_rank = 0;
+        if (w < nq) {                                // wave w: the bin of splitter w = first bin whose running count exceeds its rank
+            const u32 *h = s_hist[level == 0 ? 0 : w];
+            const u32 c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+            const u32 incl = wave_incl_scan(c0 + c1 + c2 + c3), r = s_rank[w];
+            const u64 over = __ballot(incl > r);
+            const int l = (int)__builtin_ctzll(over);            // (over != 0: the rank is below the number of codes with this prefix)
+            if ((int)lane == l) {
+                u32 before = incl - (c0 + c1 + c2 + c3), bin = 4 * lane;
+                if (before + c0 <= r) { before += c0; bin++;
+                    if (before + c1 <= r) { before += c1; bin++;
+                        if (before + c2 <= r) { before += c2; bin++; } } }
+                new_prefix = (s_prefix[w] << (level < 3 ? 8 : 6)) | bin;
+                new_rank = r - before;
             }
-            __syncthreads();
+            new_prefix = __shfl(new_prefix, l, COL_WAVE);
+            new_rank = __shfl(new_rank, l, COL_WAVE);
         }
+        __syncthreads();
+        if (w < nq && lane == 0) { s_prefix[w] = new_prefix; s_rank[w] = new_rank; }
+        __syncthreads();
     }
-    const u32 step = count / world;
-    for (u32 q = threadIdx.x + 1; q < world; q += 1024) splitters[q - 1] = s[q * step];
+    if (tid < nq) splitters[tid] = s_prefix[tid];
 }
 
 // One block per tile of the radix scatter that groups the spheres by owner: Morton code of every row under the
@@ -640,7 +670,7 @@ int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *ran
 // (256 * ceil(n / col_radix_tile(n, 4, 4)) words) and owner_counts[0..world).
 int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint32_t samples, const void *rows, uint32_t n,
                        void *range8, uint32_t *splitters, uint32_t *dest, uint32_t *hist, uint32_t *owner_counts, int coord_bytes) {
-    if (world == 0 || world > 256 || (uint64_t)world * (samples + 2) > SPL_MAX || samples + 2 < world) return COL_EINVAL;
+    if (world == 0 || world > SPL_Q + 1 || (uint64_t)world * (samples + 2) > SPL_MAX || samples + 2 < world) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
     COL_BY_COORD((k_splitters<float><<<dim3(1), dim3(1024), 0, s>>>((const float4 *)gathered, world, samples, (float *)range8, splitters)),
