@@ -338,7 +338,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
                     g = (u32)(((u64)d * nblocks + b) * 32 + min(i - s_dstart[d], 31u));
                 }
             }
-            if (DIAG && (dbg & 384)) {                         // timing ablations: stores at system (128) / agent (256) scope
+            if (DIAG && (dbg & 16384)) {                       // timing ablation: (key, value) pairs interleaved in ONE output
+                if constexpr (V_LDS && sizeof(K) == 4 && VB == 4)      // array of 8 n bytes at keys_out: a digit run is one 256-byte piece
+                    reinterpret_cast<uint2 *>(keys_out)[g] = make_uint2(kk, s_vals[i]);
+            } else if (DIAG && (dbg & 384)) {                  // timing ablations: stores at system (128) / agent (256) scope
                 if (dbg & 128) {
                     st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&keys_out[g], kk);
                     if (V_LDS) st_scope<__HIP_MEMORY_SCOPE_SYSTEM>(&vals_out[g], s_vals[i]);

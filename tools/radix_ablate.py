@@ -11,7 +11,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.RandomState(4)
 keys = rng.randint(0, 2 ** 30, size=n).astype(np.uint32)
 kin, vin = hip.Buffer(ctx, hostbuf=keys), hip.Buffer(ctx, hostbuf=np.arange(n, dtype=np.uint32))
-kout, vout = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+kout, vout = hip.Buffer(ctx, n * 8), hip.Buffer(ctx, n * 4)      # (kout: room for mode 16384's interleaved pairs)
 tile = call.col_radix_tile(n, 4, 4); nb = -(-n // tile)
 hist = hip.Buffer(ctx, 256 * nb * 4)
 ss = hip.Buffer(ctx, call.col_scan_scratch_bytes(256 * nb))
@@ -24,7 +24,7 @@ ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
 modes = ((0, "production"), (1 << 30, "production (diag instance)"), (2, "coalesced write"), (4, "blockIdx tile order"),
          (64, "non-temporal loads"), (32768, "4 MiB output window (stores hit L2)"),
-         (8192, "every run an aligned 128-byte cell of its own"), (1024, "one resident block per CU (+18 KB LDS)"))
+         (8192, "every run an aligned 128-byte cell of its own"), (16384, "(key, value) pairs interleaved in one output"), (1024, "one resident block per CU (+18 KB LDS)"))
 if len(sys.argv) > 2:
     want = set(int(x) for x in sys.argv[2].split(","))
     modes = tuple(m for m in modes if m[0] in want)
