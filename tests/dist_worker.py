@@ -211,6 +211,7 @@ def main():
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
     halo_slot = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
     part_slot = int(sys.argv[8]) if len(sys.argv) > 8 and int(sys.argv[8]) > 0 else None
+    check = sys.argv[9] if len(sys.argv) > 9 else "brute"      # "single": against the single-GPU path (large scenes)
     coord_dtype = np.dtype(sys.argv[7]) if len(sys.argv) > 7 else np.dtype("float32")
     import torch  # noqa: F401
     import torch.distributed as dist
@@ -245,16 +246,31 @@ def main():
     gathered = [None] * world
     dist.gather_object((pairs, stats), gathered if rank == 0 else None, dst=0)
     if rank == 0:
-        import oracle
-        cnt, ref = oracle.brute_force(coords, radii)
-        expect = set(map(tuple, ref.tolist()))
-        got = []
-        for p, _ in gathered:
-            got += [tuple(sorted(t)) for t in p.tolist()]
         parity_ok = all(s.get("rank_parity", "ok") == "ok" for _, s in gathered)
-        result = {"ok": len(got) == len(set(got)) == cnt and set(got) == expect and total == cnt and parity_ok,
-                  "expected": cnt, "found": len(got), "unique": len(set(got)), "global_count": total,
-                  "stats": [s for _, s in gathered], "world": world, "partition": partition, "mode": mode}
+        if check == "single":
+            # large scenes: the reference pair set is the single-GPU path's (itself oracle-exact: test_pipeline_parity)
+            from collision_amd.collision import Collider
+            from tests.util import packed_pairs, run_collider
+            cq = hip.CommandQueue(ctx)
+            cnt, ref = run_collider(ctx, cq, Collider(ctx, n, 64, 256, coord_dtype), coords, radii, 1 << 24)
+            assert cnt <= 1 << 24
+            got = np.concatenate([p for p, _ in gathered]).reshape(-1, 2)
+            g = packed_pairs(np.stack([got.min(axis=1), got.max(axis=1)], axis=1))
+            w = packed_pairs(np.stack([ref.min(axis=1), ref.max(axis=1)], axis=1))
+            same = len(g) == len(w) and bool((g == w).all())
+            unique = int(len(g) - (np.diff(g) == 0).sum()) if len(g) else 0
+            result = {"ok": same and unique == len(g) and total == cnt and parity_ok, "expected": cnt, "found": len(g),
+                      "unique": unique, "global_count": total}
+        else:
+            import oracle
+            cnt, ref = oracle.brute_force(coords, radii)
+            expect = set(map(tuple, ref.tolist()))
+            got = []
+            for p, _ in gathered:
+                got += [tuple(sorted(t)) for t in p.tolist()]
+            result = {"ok": len(got) == len(set(got)) == cnt and set(got) == expect and total == cnt and parity_ok,
+                      "expected": cnt, "found": len(got), "unique": len(set(got)), "global_count": total}
+        result.update({"stats": [s for _, s in gathered], "world": world, "partition": partition, "mode": mode})
         Path(out).write_text(json.dumps(result))
         print(json.dumps(result))
     dist.barrier()

@@ -36,12 +36,13 @@ def test_hash_owner_is_balanced():
     assert counts.min() > 0.9 * (1 << 13) and counts.max() < 1.1 * (1 << 13)
 
 
-def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32", part_slot=0):
+def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32", part_slot=0,
+         check="brute"):
     out = tmp_path / ("result_%s_%s_%d.json" % (mode, partition, world))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"),
-           mode, partition, str(n), str(out), kind, str(halo_slot), dtype, str(part_slot)]
+           mode, partition, str(n), str(out), kind, str(halo_slot), dtype, str(part_slot), check]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     return json.loads(out.read_text())
@@ -120,6 +121,20 @@ def test_halo_slot_overflow_is_repaired_on_the_gpu(tmp_path):
     res = _run(3, "gpu", "morton", 30000, tmp_path, "clustered", port=29646, halo_slot=64)
     assert res["ok"], res
     assert all(s["repeats"] >= 1 for s in res["stats"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,partition,kind,n", [(4, "morton", "uniform", 1200000), (3, "morton", "clustered", 150000),
+                                                    (2, "hash", "uniform", 300000)])
+def test_gloo_gpu_rehearsal_at_size(tmp_path, world, partition, kind, n):
+    """The protocol at sizes near the bench's (hundreds of thousands of spheres per rank: big tiles, the MSD plan,
+    adapted slots): the union of the ranks' pairs against the single-GPU path on the whole scene, plus the per-rank
+    parity against the oracle."""
+    res = _run(world, "gpu", partition, n, tmp_path, kind, port=29660 + world, check="single")
+    assert res["ok"], {k: v for k, v in res.items() if k != "stats"}
+    assert all(s["rank_parity"] == "ok" for s in res["stats"])
+    if partition == "morton" and kind == "uniform":      # eight boxes per region keep the halo a thin shell
+        assert max(s["ghosts"] for s in res["stats"]) < 0.25 * n / world
 
 
 @pytest.mark.gpu
