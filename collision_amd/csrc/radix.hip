@@ -35,9 +35,11 @@ constexpr int RDIG = 256;           // 8-bit digits
 //   MID   256 x 16 = 4096 pairs  up to BIG_N pairs, and for 8-byte keys (LDS);
 //   BIG   512 x 16 = 8192 pairs  above: the digit runs of a tile are ~128 bytes, a full L2 line, so the
 //                                stores no longer depend on the runs of neighbouring tiles meeting in L2.
-constexpr int IT_BIG = 16, IT_SMALL = 4;
-constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256;
-constexpr uint64_t SMALL_N = 1u << 20, BIG_N = 16u << 20;   // tools/radix_tile_sweep.py
+//   HUGE  512 x 32 = 16384 keys  from HUGE_N keys, u32 keys WITHOUT values (k_scatter_huge): ~256-byte runs -- one
+//                                whole line and two partial ones instead of two partial ones per run.
+constexpr int IT_BIG = 16, IT_SMALL = 4, IT_HUGE = 32;
+constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256, NT_HUGE = 512;
+constexpr uint64_t SMALL_N = 1u << 20, BIG_N = 16u << 20, HUGE_N = 32u << 20;   // tools/radix_tile_sweep.py
 constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
 
 template <int B> struct Val;
@@ -360,6 +362,110 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 }
 
 
+// ---- the 16384-key tile (u32 keys WITHOUT values, from HUGE_N keys) ----
+// Same ranking and the same tile-sorted image as k_scatter with twice the tile: digit runs of ~256 bytes (one whole
+// line and two partial ones instead of two partial ones), 0.147 instead of 0.163 ms per 64 Mi-key pass.  Two 8-wave
+// blocks per CU leave 128 VGPRs per thread, so the staged keys stay in LDS through the ranking (read back one item
+// at a time) and come into registers only to cross the barrier after which the image -- the same 64 KB -- is
+// overwritten in tile-sorted order.
+// Not for (key, value) pairs: with the values taking their turn in the one image after the keys (a second 64 KB
+// would leave one block per CU; ranks packed two to a register, the slots' digits four to a register, the values
+// waiting in registers from the common load) the pass took 0.279 ms against 0.235 for the 8192-pair tile --
+// bit-exact on the GPU suite, and dropped.
+// RAGGED = the instance for the input's last, partial tile (one block, launched on its own: tile `first_tile`): its
+// guarded element-wise loads would otherwise share the register allocation of the full-tile instance, whose asm
+// loads must never be spilled (hipcc does not know they are in flight).
+template <bool RAGGED>
+__global__ __launch_bounds__(NT_HUGE, 4) void k_scatter_huge(const u32 *__restrict__ keys_in, u32 *__restrict__ keys_out,
+                                                             uint64_t n, u32 nblocks, u32 first_tile, int shift,
+                                                             const u32 *__restrict__ offsets) {
+    constexpr int NT = NT_HUGE, IT = IT_HUGE, TILE = NT * IT, NW = NT / COL_WAVE, SLICE = COL_WAVE * IT;
+    __shared__ __attribute__((aligned(16))) u32 s_img[TILE];
+    __shared__ u32 s_cnt[NW][RDIG];
+    __shared__ u32 s_goff[RDIG];
+    __shared__ u32 s_ws[NW];
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32 tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
+    u32 b = blockIdx.x;                                   // XCD-contiguous tile ranges, as in k_scatter
+    if (!RAGGED) {
+        const u32 q = gridDim.x / 8, r = gridDim.x % 8, xcd = b % 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    b += first_tile;
+    const uint64_t tile_base = (uint64_t)b * TILE;
+    const u32 valid = RAGGED ? (u32)(n - tile_base) : (u32)TILE;
+    const u32 my_offset = tid < RDIG ? offsets[(uint64_t)tid * nblocks + b] : 0u;
+    for (u32 i = lane; i < RDIG; i += COL_WAVE) s_cnt[w][i] = 0;      // (this wave's own counters)
+    u32 *stage = s_img + w * SLICE;
+    v4u kq[IT / 4];
+    const u32 e0 = w * SLICE + lane * 4;                  // tile-relative index of this lane's first key of vector 0
+    if (!RAGGED) {
+#pragma unroll
+        for (int j = 0; j < IT / 4; j++)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kq[j]) : "v"(keys_in + tile_base + e0 + j * (COL_WAVE * 4)) : "memory");
+#pragma unroll
+        for (int j = 0; j < IT / 4; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(kq[j])::"memory");
+    } else {
+#pragma unroll
+        for (int j = 0; j < IT / 4; j++) {
+            const u32 e = e0 + j * (COL_WAVE * 4);
+            for (int c = 0; c < 4; c++) kq[j][c] = e + c < valid ? keys_in[tile_base + e + c] : 0xFFFFFFFFu;   // padding sorts last, never stored
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < IT / 4; j++) *reinterpret_cast<v4u *>(stage + j * (COL_WAVE * 4) + lane * 4) = kq[j];
+    __builtin_amdgcn_wave_barrier();          // (LDS operations of one wave execute in order; the slice and the counters are its own)
+
+    // rank inside (wave, digit): k_scatter's scheme, the key read back from the slice item by item
+    u32 pos[IT];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 d = digit_of(stage[k * COL_WAVE + lane], shift);
+        const u64 peers = match8(d);
+        const u32 below = mbcnt(peers);
+        const u32 prev = s_cnt[w][d];
+        if (below == 0) s_cnt[w][d] = prev + (u32)__popcll(peers);
+        pos[k] = prev + below;
+    }
+    __syncthreads();
+    {
+        u32 c[NW], tot = 0;
+        if (tid < RDIG) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) { c[i] = s_cnt[i][tid]; tot += c[i]; }
+        }
+        u32 total;
+        const u32 dstart = block_excl_scan<NT>(tot, s_ws, &total);      // threads >= 256 contribute 0
+        if (tid < RDIG) {
+            u32 run = dstart;
+#pragma unroll
+            for (int i = 0; i < NW; i++) { s_cnt[i][tid] = run; run += c[i]; }
+            s_goff[tid] = my_offset - dstart;      // global position of tile-sorted slot i with digit d is s_goff[d] + i
+        }
+    }
+    __syncthreads();
+    {
+        u32 key[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            key[k] = stage[k * COL_WAVE + lane];
+            pos[k] += s_cnt[w][digit_of(key[k], shift)];
+        }
+        __syncthreads();                      // every wave holds its keys: the slices may be overwritten
+#pragma unroll
+        for (int k = 0; k < IT; k++) s_img[pos[k]] = key[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+        const u32 i = k * NT + tid;
+        if (i < valid) {
+            const u32 kk = s_img[i];
+            keys_out[s_goff[digit_of(kk, shift)] + i] = kk;
+        }
+    }
+}
+
 // ---- MSD finish: one block sorts one top-digit bucket on its remaining low bits ----
 // col_radix_sort_msd (small inputs, launch-bound): ONE global pass on the top 8 significant bits
 // (k_scatter, shift BS_SHIFT) leaves 256 buckets; a bucket of up to BS_CAP pairs is then sorted on
@@ -613,20 +719,23 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 // Process-wide diagnostics switches (col_debug_radix / col_debug_radix_tile): they change the kernels of
 // EVERY caller in the process and are not synchronised -- set them from one thread, with no sort in flight.
 int g_radix_dbg = 0;
-int g_radix_tile_override = 0;      // 0 = automatic, else 1024 / 4096 / 8192
+int g_radix_tile_override = 0;      // 0 = automatic, else 1024 / 4096 / 8192 / 16384
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline u32 tile_auto(uint64_t n, int key_bytes) {
+inline bool huge_ok(int key_bytes, int val_bytes) { return key_bytes == 4 && val_bytes == 0; }
+inline u32 tile_auto(uint64_t n, int key_bytes, int val_bytes) {
     u32 t = n < SMALL_N ? (u32)(NT_SMALL * IT_SMALL) : n < BIG_N ? (u32)(NT_MID * IT_BIG) : (u32)(NT_BIG * IT_BIG);
+    if (n >= HUGE_N && huge_ok(key_bytes, val_bytes)) t = (u32)(NT_HUGE * IT_HUGE);
     if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
     return t;
 }
-inline u32 tile_for(uint64_t n, int key_bytes) {
-    if (!g_radix_tile_override) return tile_auto(n, key_bytes);
+inline u32 tile_for(uint64_t n, int key_bytes, int val_bytes) {
+    if (!g_radix_tile_override) return tile_auto(n, key_bytes, val_bytes);
     u32 t = (u32)g_radix_tile_override;
+    if (t > (u32)(NT_BIG * IT_BIG) && !huge_ok(key_bytes, val_bytes)) t = (u32)(NT_BIG * IT_BIG);
     if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
     return t;
 }
-inline u32 tiles_of(uint64_t n, int key_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes)); }
+inline u32 tiles_of(uint64_t n, int key_bytes, int val_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes, val_bytes)); }
 // The most tiles any n' <= n can have: the tile GROWS with n, so a smaller input may have more tiles (and a
 // larger histogram) than n itself.  Scratch is sized with this bound, so one scratch buffer sized for n
 // serves every n' <= n (col_collide on a varying number of owned spheres: collision_amd/multi.py).
@@ -650,14 +759,15 @@ inline u32 hist_group(u32 nblocks) {
 }
 
 template <typename K>
-int launch_hist(hipStream_t s, const void *keys, uint64_t n, int pass, u32 *hist) {
-    const u32 tile = tile_for(n, (int)sizeof(K));
-    const u32 nb = tiles_of(n, (int)sizeof(K)), g = hist_group(nb);
+int launch_hist(hipStream_t s, const void *keys, uint64_t n, int val_bytes, int pass, u32 *hist) {
+    const u32 tile = tile_for(n, (int)sizeof(K), val_bytes);
+    const u32 nb = tiles_of(n, (int)sizeof(K), val_bytes), g = hist_group(nb);
     dim3 grid((unsigned)col_ceil_div(nb, g)), block(RT);
     const K *k = (const K *)keys;
     if (tile == (u32)(NT_SMALL * IT_SMALL)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else if (tile == (u32)(NT_MID * IT_BIG)) k_hist<K, NT_MID * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
-    else k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
+    else if (tile == (u32)(NT_BIG * IT_BIG)) k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
+    else k_hist<K, NT_HUGE * IT_HUGE><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -701,13 +811,28 @@ int launch_scatter_it(hipStream_t s, const void *keys, void *keys_out, const voi
 template <typename K>
 int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *vals, void *vals_out,
                    uint64_t n, int vb, int shift, const u32 *offsets) {
-    const u32 tile = tile_for(n, (int)sizeof(K));
+    if (!vals || !vals_out) vb = 0;
+    const u32 tile = tile_for(n, (int)sizeof(K), vb);
     if (tile == (u32)(NT_SMALL * IT_SMALL))
         return launch_scatter_it<K, IT_SMALL, NT_SMALL>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
     if (tile == (u32)(NT_MID * IT_BIG))
         return launch_scatter_it<K, IT_BIG, NT_MID>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
-    if constexpr (sizeof(K) == 4)
+    if constexpr (sizeof(K) == 4) {
+        if (tile == (u32)(NT_HUGE * IT_HUGE)) {          // (u32 keys without values only: tile_for)
+            constexpr uint64_t T = NT_HUGE * IT_HUGE;
+            const u32 nb = (u32)col_ceil_div(n, T), nfull = (u32)(n / T);
+            if (nfull) {
+                k_scatter_huge<false><<<dim3(nfull), dim3(NT_HUGE), 0, s>>>((const u32 *)keys, (u32 *)keys_out, n, nb, 0, shift, offsets);
+                COL_LAUNCH_OK();
+            }
+            if (nb > nfull) {                              // the partial last tile
+                k_scatter_huge<true><<<dim3(1), dim3(NT_HUGE), 0, s>>>((const u32 *)keys, (u32 *)keys_out, n, nb, nfull, shift, offsets);
+                COL_LAUNCH_OK();
+            }
+            return COL_OK;
+        }
         return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
+    }
     return COL_EINVAL;
 }
 
@@ -756,7 +881,7 @@ extern "C" {
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
 int col_debug_radix_tile(int tile) {
-    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG) return COL_EINVAL;
+    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE) return COL_EINVAL;
     g_radix_tile_override = tile;
     return COL_OK;
 }
@@ -768,7 +893,9 @@ int col_debug_radix_stamps(uint64_t *out, int reset) {
     return COL_OK;
 }
 
-uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) { (void)val_bytes; return tile_for(n, key_bytes); }
+uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) {
+    return tile_for(n, key_bytes, wide_value(val_bytes) ? 4 : val_bytes);       // (wide values are sorted as (key, index) pairs)
+}
 
 // Monotone in n: sized for the largest histogram any n' <= n can need (see max_tiles_upto), so a scratch
 // buffer sized for n serves every smaller sort / col_collide call as well.
@@ -787,8 +914,8 @@ int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_byte
                         uint32_t *hist) {
     if (bad_sizes(n, key_bytes, val_bytes) || pass < 0 || pass >= key_bytes) return COL_EINVAL;
     if (n == 0) return COL_OK;
-    return key_bytes == 4 ? launch_hist<uint32_t>(col_stream(stream), keys, n, pass, hist)
-                          : launch_hist<uint64_t>(col_stream(stream), keys, n, pass, hist);
+    return key_bytes == 4 ? launch_hist<uint32_t>(col_stream(stream), keys, n, val_bytes, pass, hist)
+                          : launch_hist<uint64_t>(col_stream(stream), keys, n, val_bytes, pass, hist);
 }
 
 int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
@@ -810,7 +937,7 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
     if (n == 0) return COL_OK;
     if (!scratch || !vals || !vals_out) return COL_EINVAL;
     if (n > COL_MSD_MAX_N) return COL_EINVAL;
-    const u32 tile = tile_auto(n, 4);                     // (a forced tile class does not apply here)
+    const u32 tile = tile_auto(n, 4, 4);                  // (a forced tile class does not apply here)
     hipStream_t s = col_stream(stream);
     const size_t nb = col_ceil_div(n, tile);
     char *p = (char *)scratch;
@@ -863,7 +990,7 @@ int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void
     if (n == 0) return COL_OK;
     if (!scratch) return COL_ENOSCRATCH;
     hipStream_t s = col_stream(stream);
-    const size_t nb = tiles_of(n, key_bytes);
+    const size_t nb = tiles_of(n, key_bytes, val_bytes);
     char *p = (char *)scratch;
     u32 *hist = (u32 *)p;              p += align256((size_t)RDIG * nb * sizeof(u32));
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));

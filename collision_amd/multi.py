@@ -593,11 +593,11 @@ class DistributedCollider:
             self.stats["ghosts"] = ghosts
             self.stats["halo_slot"], self.stats["partition_slot"] = self.slot, self.part_slot
             want = max(4096, roundUp(longest + longest // 2 + 1024, 1024))
-            want_p = max(1024, roundUp(longest_part + longest_part // 4 + 1024, 1024))
+            want_p = max(1024, roundUp(longest_part + longest_part // 16 + 2048, 1024))      # padding travels: keep it small
             again = False
             if longest_part > self.part_slot:
                 self.part_slot, again = min(want_p, cap), True
-            elif want_p < self.part_slot // 2:
+            elif 20 * want_p <= 17 * self.part_slot:        # (shrink with hysteresis: lists that breathe by a few % keep their slot)
                 self.part_slot = want_p
             if longest > self.slot:
                 self.slot, again = min(want, cap), True

@@ -212,6 +212,51 @@ def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
         np.testing.assert_array_equal(download(cq, vo, np.uint8, vals.shape), vals[order])
 
 
+def test_huge_tile_kernel(hip_env):
+    """The 16384-key tile (u32 keys WITHOUT values; automatic from 32 Mi keys) has a kernel of its own
+    (k_scatter_huge) and a separate instance for the input's partial last tile: forced here on small inputs --
+    only a partial tile, exact multiples, ragged tails, constant and blocky keys -- and at its automatic size.
+    Sorts with values keep the 8192-pair tile (a forced 16384 falls back to it)."""
+    from collision_amd._lib import call, cdll
+    ctx, cq = hip_env
+    huge = 32 << 20
+    assert call.col_radix_tile(huge - 1, 4, 0) == 8192 and call.col_radix_tile(huge, 4, 0) == 16384
+    assert call.col_radix_tile(huge, 4, 4) == 8192 and call.col_radix_tile(huge, 4, 1) == 8192 and call.col_radix_tile(huge, 8, 0) == 4096
+    rs = np.random.RandomState(11)
+
+    def check(keys, with_values=False):
+        n = len(keys)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = upload(ctx, keys), upload(ctx, vals)
+        ko, vo = hip.Buffer(ctx, keys.nbytes), hip.Buffer(ctx, vals.nbytes)
+        vbytes = 4 if with_values else 0
+        scratch = hip.Buffer(ctx, call.col_radix_scratch_bytes(n, 4, vbytes))
+        call.col_radix_sort(cq.stream, kb.ptr, ko.ptr, vb.ptr if with_values else None, vo.ptr if with_values else None,
+                            n, 4, vbytes, scratch.ptr, 0)
+        out = download(cq, ko, np.uint32, n)
+        if with_values:
+            _check_stable_sort(keys, out, download(cq, vo, np.uint32, n))
+        else:
+            np.testing.assert_array_equal(out, np.sort(keys))
+
+    assert cdll().col_debug_radix_tile(16384) == 0
+    try:
+        assert call.col_radix_tile(1000, 4, 0) == 16384 and call.col_radix_tile(1000, 4, 4) == 8192
+        for n in (1, 100, 16383, 16384, 16385, 3 * 16384, 3 * 16384 + 77, 40 * 16384 + 16383, 1000003):
+            check(rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32))
+        n = 5 * 16384 + 4001
+        for keys in (np.full(n, 3, np.uint32), (np.arange(n, dtype=np.uint32) // 777) % 5, np.zeros(n, np.uint32),
+                     np.arange(n, dtype=np.uint32)[::-1].copy(), rs.randint(0, 2 ** 30, size=n).astype(np.uint32)):
+            check(keys.astype(np.uint32))
+        check(rs.randint(0, 2 ** 32, size=100001, dtype=np.uint64).astype(np.uint32), with_values=True)
+    finally:
+        cdll().col_debug_radix_tile(0)
+    for n in (huge, huge + 5):                                     # automatic: exact multiple, 5-key last tile
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+        k[::7] = k[3]
+        check(k)
+
+
 def _check_stable_sort(keys, out_keys, out_vals):
     """out_vals must be THE stable argsort of keys (values were arange), out_keys the sorted keys -- checked
     without an argsort: a permutation that gathers the sorted keys and ascends inside runs of equal keys."""

@@ -44,9 +44,13 @@ for mode, what in modes:
         mode, what, t[0], t[len(t) // 2], n * 16 / t[len(t) // 2] / 1e6, n * 16 / t[len(t) // 2] / 1e6 / 8000,
         " ".join("%.3f" % v for v in times[mode])))
 cdll().col_debug_radix(0)
-# keys only
+# keys only (its own histogram: from 32 Mi keys a key-only sort uses the 16384-key tile)
+nb0 = -(-n // call.col_radix_tile(n, 4, 0))
+hist0 = hip.Buffer(ctx, 256 * nb0 * 4)
+call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 0, 0, hist0.ptr)
+call.col_scan_u32(cq.stream, hist0.ptr, 256 * nb0, ss.ptr)
 def run0():
-    call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, None, None, n, 4, 0, 0, hist.ptr)
+    call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, None, None, n, 4, 0, 0, hist0.ptr)
 for mode in (0,):
     cdll().col_debug_radix(mode)
     run0(); cq.finish()
