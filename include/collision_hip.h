@@ -136,7 +136,9 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
                    uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back);
 /* One pass of the production sort, for profiling and per-pass parity:
  * histogram (digit-major, hist[d*nblocks+b]) -> scan -> scatter. */
-uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes);   /* elements per block for an n-element sort */
+uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes);   /* elements per block for an n-element sort: it depends
+                                           on all three (1024 / 4096 / 8192, and 16384 for u32 key-only sorts from 32 Mi
+                                           keys); pass the SAME val_bytes to the histogram and the scatter of a pass */
 int col_radix_histogram(void *stream, const void *keys, uint64_t n, int key_bytes, int val_bytes,
                         int pass, uint32_t *hist);
 int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
@@ -181,7 +183,7 @@ void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_ch
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
                                            64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU,
                                            32768 = every store lands in a 4 MiB window */
-int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192; 0 = automatic).  Set it BEFORE sizing
+int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192, 16384; 0 = automatic).  Set it BEFORE sizing
                                            scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it. */
 int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
 /* stats: 8 x uint64 (steps, descents, leaf tests, leaf hits, steps within 1k/2k/4k/8k positions of the block start) */
