@@ -466,6 +466,18 @@ def main():
         extra["per_rank"] = {"owned_spheres_rank0": engine.stats.get("owned"), "ghost_queries_rank0": engine.stats.get("ghosts"),
                              "partition_slot_records": engine.stats.get("partition_slot"),
                              "halo_slot_records": engine.stats.get("halo_slot"), "repeated_steps": engine.repeats}
+        # the same spheres with a coherent arrival: each step's input is what the rank owned after the previous one
+        # (adopt_owned: a simulation advancing positions in place).  Nothing has moved, so after the first step every
+        # sphere is kept by its rank and the repartition slots travel nearly empty.  NOT the headline workload.
+        def coherent_step():
+            engine.adopt_owned()
+            engine.step()
+        dtc = timed_region(coherent_step, engine.synchronize)
+        extra["coherent_arrival"] = {"workload": "%d x 2M spheres, input of a step = owned spheres of the previous one" % world,
+                                     "ms_per_step": round(dtc / args.steps * 1e3, 4),
+                                     "m_spheres_per_s": round(N_PER_RANK_MULTI * world / (dtc / args.steps) / 1e6, 2),
+                                     "partition_slot_records": engine.stats.get("partition_slot"),
+                                     "pairs_found": engine.global_pair_count()}
         # the same protocol at 1 M spheres per rank (round 1's line), reported beside the config-4 workload
         del engine
         engine1 = make_engine(N_SPHERES)

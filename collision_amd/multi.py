@@ -351,6 +351,13 @@ class HipEngine(ProtocolOps):
         self.gids_in[:n] = torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32)).to(self.device)
         return n
 
+    def swap_input_and_owned(self):
+        """The owned arrays become the input arrays and vice versa (stream-ordered: nothing is copied)."""
+        self.rows_in, self.owned_rows = self.owned_rows, self.rows_in
+        self.gids_in, self.owned_gids = self.owned_gids, self.gids_in
+        for k in ("rows_in", "gids_in", "owned_rows", "owned_gids"):
+            self._p[k] = getattr(self, k).data_ptr()
+
     # -- streams
     def begin_step(self, sampled):
         """Per-step flags are cleared by the sample launch when there is one."""
@@ -522,9 +529,22 @@ class DistributedCollider:
             self.part_slot = int(partition_slot)
         self.repeats = 0                         # steps repeated because a slot overflowed
         self._dirty = False
+        self.own_rows = self.own_gids = None
+        self.n_owned = 0
 
     def set_local_spheres(self, coords4, radii, gids):
         self.n_in = self.engine.load(coords4, radii, gids)
+
+    def adopt_owned(self):
+        """What this rank owns after the last step() becomes its input for the next one: a simulation that advances
+        positions where the spheres live.  Nothing is copied (the engine swaps its input and owned arrays, in stream
+        order) and nothing waits.  Spheres that have not moved far stay with their rank: they are 'kept' by the next
+        repartition and never travel, and synchronize() lets the repartition slots shrink to what still moves."""
+        if self.own_rows is None or self.own_rows is self.engine.rows_in:
+            return                            # (no repartition ran: the input already is what the rank owns)
+        self.engine.swap_input_and_owned()
+        self.n_in = self.n_owned
+        self.own_rows, self.own_gids = self.engine.rows_in, self.engine.gids_in
 
     # -- one step ------------------------------------------------------------------------------
     def step(self):

@@ -56,6 +56,10 @@ class OracleEngine(_protocol_ops()):
         self.gids_in[:n] = self.torch.from_numpy(np.asarray(gids).astype(np.uint32).view(np.int32))
         return n
 
+    def swap_input_and_owned(self):
+        self.rows_in, self.owned_rows = self.owned_rows, self.rows_in
+        self.gids_in, self.owned_gids = self.owned_gids, self.gids_in
+
     def begin_step(self, sampled):
         self._longest = self._ghosts = self._longest_part = 0
 
@@ -212,6 +216,7 @@ def main():
     halo_slot = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
     part_slot = int(sys.argv[8]) if len(sys.argv) > 8 and int(sys.argv[8]) > 0 else None
     check = sys.argv[9] if len(sys.argv) > 9 else "brute"      # "single": against the single-GPU path (large scenes)
+    adopt = len(sys.argv) > 10 and sys.argv[10] == "adopt"     # feed the owned spheres back as the next step's input
     coord_dtype = np.dtype(sys.argv[7]) if len(sys.argv) > 7 else np.dtype("float32")
     import torch  # noqa: F401
     import torch.distributed as dist
@@ -237,6 +242,15 @@ def main():
     for _ in range(2):                       # twice: buffers are reused across steps
         dc.step()
     dc.synchronize()
+    if adopt:
+        # a simulation that advances positions in place: what a rank owns is its next input (nothing moves here, so
+        # after the slots have adapted nothing travels: every list is empty and every sphere is 'kept')
+        for _ in range(3):
+            dc.adopt_owned()
+            dc.step()
+            dc.synchronize()
+        dc.adopt_owned()
+        dc.step()
     pairs = dc.local_pairs()
     total = dc.global_pair_count()
     stats = dict(dc.stats)

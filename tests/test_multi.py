@@ -37,12 +37,12 @@ def test_hash_owner_is_balanced():
 
 
 def _run(world, mode, partition, n, tmp_path, kind="uniform", port=29611, halo_slot=0, dtype="float32", part_slot=0,
-         check="brute"):
+         check="brute", adopt=""):
     out = tmp_path / ("result_%s_%s_%d.json" % (mode, partition, world))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"),
-           mode, partition, str(n), str(out), kind, str(halo_slot), dtype, str(part_slot), check]
+           mode, partition, str(n), str(out), kind, str(halo_slot), dtype, str(part_slot), check, adopt]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     return json.loads(out.read_text())
@@ -78,6 +78,14 @@ def test_partition_slot_overflow_is_repaired(tmp_path):
     res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29643, part_slot=16)
     assert res["ok"], res
     assert all(s["repeats"] >= 1 and s["partition_slot"] > 16 for s in res["stats"])
+
+
+def test_adopting_the_owned_spheres_keeps_the_result(tmp_path):
+    """adopt_owned(): what a rank owns becomes its next input (nothing is copied).  The pair set stays exact, and
+    once the slots have adapted nothing travels any more: every sphere is kept by its rank."""
+    res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29644, adopt="adopt")
+    assert res["ok"], res
+    assert all(s["partition_slot"] <= 4096 for s in res["stats"])
 
 
 @pytest.mark.parametrize("partition,kind", [("hash", "uniform"), ("morton", "uniform"), ("morton", "clustered")])
@@ -135,6 +143,13 @@ def test_gloo_gpu_rehearsal_at_size(tmp_path, world, partition, kind, n):
     assert all(s["rank_parity"] == "ok" for s in res["stats"])
     if partition == "morton" and kind == "uniform":      # eight boxes per region keep the halo a thin shell
         assert max(s["ghosts"] for s in res["stats"]) < 0.25 * n / world
+
+
+@pytest.mark.gpu
+def test_adopting_the_owned_spheres_keeps_the_result_on_the_gpu(tmp_path):
+    res = _run(4, "gpu", "morton", 400000, tmp_path, "uniform", port=29645, check="single", adopt="adopt")
+    assert res["ok"], {k: v for k, v in res.items() if k != "stats"}
+    assert all(s["rank_parity"] == "ok" and s["partition_slot"] <= 8192 for s in res["stats"])
 
 
 @pytest.mark.gpu
