@@ -259,6 +259,8 @@ class ProtocolOps:
 class HipEngine(ProtocolOps):
     """Device work of one rank through the C ABI, on torch CUDA tensors (torch = memory + streams)."""
 
+    OWNED_COUNT_TIMEOUT_S = 600
+
     def __init__(self, ctx, capacity, group_size, pair_capacity, coord_dtype=np.dtype("float32")):
         import torch
         from .collision import Collider
@@ -407,13 +409,20 @@ class HipEngine(ProtocolOps):
     def owned_count(self):
         """The step's one host wait: the unpack launch writes (step number << 32 | m) into a host-visible word."""
         word, seq, ev = C.c_uint64.from_address(self._host_word), self._seq, self._owned_event
-        spins = 0
+        spins, t0 = 0, None
         while (word.value >> 32) != seq:
             spins += 1
-            if (spins & 255) == 0 and ev.query():              # the launch has completed: its store is visible
-                if (word.value >> 32) != seq:
-                    raise RuntimeError("the repartition did not publish its owned count")
-                break
+            if (spins & 255) == 0:
+                if ev.query():                                 # the launch has completed: its store is visible
+                    if (word.value >> 32) != seq:
+                        raise RuntimeError("the repartition did not publish its owned count")
+                    break
+                if (spins & 0xFFFFF) == 0:                     # (a peer that never joins the exchange must not hang this rank for ever)
+                    import time
+                    t0 = t0 or time.monotonic()
+                    if time.monotonic() - t0 > self.OWNED_COUNT_TIMEOUT_S:
+                        raise RuntimeError("no owned count after %d s: the repartition exchange did not complete"
+                                           % self.OWNED_COUNT_TIMEOUT_S)
         return int(word.value & 0xFFFFFFFF)
 
     # -- local path (main stream)
