@@ -212,17 +212,18 @@ template <typename T> __device__ __forceinline__ void wave_fold8(T (&v)[8]) {
 // needs agent-scope fences, and on this part those write back and invalidate the whole L2 under the blocks that
 // are still streaming: measured 22 us against 8 + 3 for the pair).  k_range_part: one partial per block.
 constexpr int SR_BLOCKS = 256, RU = 4;
+constexpr int RANGE_NT = 1024, REGION_NT = 512;      // threads per block of the two partial kernels (occupancy: few, long blocks)
 template <typename T>
-__global__ __launch_bounds__(256) void k_range_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, T *__restrict__ partials) {
+__global__ __launch_bounds__(RANGE_NT) void k_range_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, T *__restrict__ partials) {
     typedef typename MT<T>::V4 V4;
-    __shared__ T s_part[4][8];
+    __shared__ T s_part[RANGE_NT / 64][8];
     const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
     T v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = k < 4 ? (T)INFINITY : -(T)INFINITY;
     // RU rows in flight per thread: the loop is bound by the latency of its loads, not by their bytes
-    const u32 stride = gridDim.x * 256;
-    for (u32 i0 = blockIdx.x * 256 + tid; i0 < n; i0 += RU * stride) {
+    const u32 stride = gridDim.x * RANGE_NT;
+    for (u32 i0 = blockIdx.x * RANGE_NT + tid; i0 < n; i0 += RU * stride) {
         V4 c[RU];
 #pragma unroll
         for (int u = 0; u < RU; u++) c[u] = rows[min(i0 + u * stride, n - 1)];      // (a repeated row changes no min / max)
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_range_part(const typename MT<T>::V4 *__
     __syncthreads();
     if (tid < 8) {
         T a = s_part[0][tid];
-        for (int i = 1; i < 4; i++) { const T t = s_part[i][tid]; a = tid < 4 ? (t < a ? t : a) : (t > a ? t : a); }
+        for (int i = 1; i < RANGE_NT / 64; i++) { const T t = s_part[i][tid]; a = tid < 4 ? (t < a ? t : a) : (t > a ? t : a); }
         partials[(u64)blockIdx.x * 8 + tid] = a;
     }
 }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void k_range_fold(const typename MT<T>::V4 *__
 }
 
 // The REGION of a rank for the halo selection: COL_REGION_BOXES = 8 boxes, one per octant of the global scene range
-// (the top three bits of a sphere's Morton code), each (min centre - max r, 0, max centre + max r, 0) over the owned
+// (which side of the range's middle a centre lies on, per axis), each (min centre - max r, 0, max centre + max r, 0) over the owned
 // spheres of that octant -- conservative (exact for equal radii), which is all a halo selection needs; an octant
 // without spheres gets an inverted box that nothing overlaps.  A rank owns a Morton RANGE: inside one octant that
 // is a compact piece, while ONE box around a range that spills over an octant boundary by a few spheres would
@@ -294,27 +295,30 @@ __global__ __launch_bounds__(256) void k_range_fold(const typename MT<T>::V4 *__
 // Two launches like k_range (partials: 56 scalars per block); the fold also clears zero[0..zero_count).
 constexpr int RG_VALS = 7 * COL_REGION_BOXES;      // per octant: min x, y, z; max x, y, z; max r
 template <typename T>
-__global__ __launch_bounds__(256) void k_region_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
+__global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
                                                       T *__restrict__ partials) {
     typedef typename MT<T>::V4 V4;
-    __shared__ T s_part[4][RG_VALS];
+    __shared__ T s_part[REGION_NT / 64][RG_VALS];
     const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
     T v[COL_REGION_BOXES][7];
 #pragma unroll
     for (int o = 0; o < COL_REGION_BOXES; o++)
 #pragma unroll
         for (int k = 0; k < 7; k++) v[o][k] = k < 3 ? (T)INFINITY : -(T)INFINITY;
-    T mnx = 0, mny = 0, mnz = 0, mxx = 1, mxy = 1, mxz = 1;
-    if (range8) { mnx = range8[0]; mny = range8[1]; mnz = range8[2]; mxx = range8[4]; mxy = range8[5]; mxz = range8[6]; }
-    const u32 stride = gridDim.x * 256;
-    for (u32 i0 = blockIdx.x * 256 + tid; i0 < n; i0 += RU * stride) {
+    // octant = which side of the middle of the global range, per axis.  (Any grouping of the owned spheres gives a
+    // valid region -- the boxes only have to cover them -- so this need not be the top bits of the Morton code,
+    // whose three correctly rounded divisions per row made this kernel compute-bound.)
+    T midx = 0, midy = 0, midz = 0;
+    if (range8) { midx = (range8[0] + range8[4]) * (T)0.5; midy = (range8[1] + range8[5]) * (T)0.5; midz = (range8[2] + range8[6]) * (T)0.5; }
+    const u32 stride = gridDim.x * REGION_NT;
+    for (u32 i0 = blockIdx.x * REGION_NT + tid; i0 < n; i0 += RU * stride) {
         V4 cc[RU];
 #pragma unroll
         for (int u = 0; u < RU; u++) cc[u] = rows[min(i0 + u * stride, n - 1)];     // (a repeated row changes no min / max)
 #pragma unroll
         for (int u = 0; u < RU; u++) {
             const V4 c = cc[u];
-            const u32 oct = range8 ? morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz) >> 27 : 0u;
+            const u32 oct = range8 ? ((c.x >= midx ? 4u : 0u) | (c.y >= midy ? 2u : 0u) | (c.z >= midz ? 1u : 0u)) : 0u;
             const T e[3] = {c.x, c.y, c.z};
 #pragma unroll
             for (int o = 0; o < COL_REGION_BOXES; o++)
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void k_region_part(const typename MT<T>::V4 *_
     if (tid < (u32)RG_VALS) {
         const bool is_min = tid % 7 < 3;
         T a = s_part[0][tid];
-        for (int i = 1; i < 4; i++) { const T t = s_part[i][tid]; a = is_min ? (t < a ? t : a) : (t > a ? t : a); }
+        for (int i = 1; i < REGION_NT / 64; i++) { const T t = s_part[i][tid]; a = is_min ? (t < a ? t : a) : (t > a ? t : a); }
         partials[(u64)blockIdx.x * RG_VALS + tid] = a;
     }
 }
@@ -629,8 +633,8 @@ extern "C" {
 
 size_t col_partition_scratch_bytes(void) { return (size_t)SR_BLOCKS * RG_VALS * sizeof(double); }
 
-static inline unsigned range_blocks(uint32_t n) {
-    const uint64_t b = col_ceil_div(n, 256 * RU);
+static inline unsigned range_blocks(uint32_t n, int threads) {
+    const uint64_t b = col_ceil_div(n, (uint64_t)threads * RU);
     return (unsigned)(b < 1 ? 1 : b > SR_BLOCKS ? SR_BLOCKS : b);
 }
 
@@ -639,9 +643,9 @@ int col_partition_sample(void *stream, const void *rows, uint32_t n, uint32_t sa
                          uint32_t *zero, uint32_t zero_count, int coord_bytes) {
     if (samples == 0 || !scratch || zero_count > 256) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
-    const unsigned g = range_blocks(n), gs = blocks_for(samples);
-    COL_BY_COORD((k_range_part<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, n, (float *)scratch)),
-                 (k_range_part<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, n, (double *)scratch)));
+    const unsigned g = range_blocks(n, RANGE_NT), gs = blocks_for(samples);
+    COL_BY_COORD((k_range_part<float><<<dim3(g), dim3(RANGE_NT), 0, s>>>((const float4 *)rows, n, (float *)scratch)),
+                 (k_range_part<double><<<dim3(g), dim3(RANGE_NT), 0, s>>>((const double4 *)rows, n, (double *)scratch)));
     COL_LAUNCH_OK();
     COL_BY_COORD((k_range_fold<float><<<dim3(gs), dim3(256), 0, s>>>((const float4 *)rows, n, samples, (const float *)scratch, g, (float4 *)payload, zero, zero_count)),
                  (k_range_fold<double><<<dim3(gs), dim3(256), 0, s>>>((const double4 *)rows, n, samples, (const double *)scratch, g, (double4 *)payload, zero, zero_count)));
@@ -655,9 +659,9 @@ int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *ran
                      uint32_t zero_count, int coord_bytes) {
     if (!scratch || zero_count > 256) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
-    const unsigned g = range_blocks(n);
-    COL_BY_COORD((k_region_part<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, n, (const float *)range8, (float *)scratch)),
-                 (k_region_part<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, n, (const double *)range8, (double *)scratch)));
+    const unsigned g = range_blocks(n, REGION_NT);
+    COL_BY_COORD((k_region_part<float><<<dim3(g), dim3(REGION_NT), 0, s>>>((const float4 *)rows, n, (const float *)range8, (float *)scratch)),
+                 (k_region_part<double><<<dim3(g), dim3(REGION_NT), 0, s>>>((const double4 *)rows, n, (const double *)range8, (double *)scratch)));
     COL_LAUNCH_OK();
     COL_BY_COORD((k_region_fold<float><<<dim3(1), dim3(256), 0, s>>>((const float *)scratch, g, (float4 *)out, zero, zero_count)),
                  (k_region_fold<double><<<dim3(1), dim3(256), 0, s>>>((const double *)scratch, g, (double4 *)out, zero, zero_count)));
