@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_range_fold(const typename MT<T>::V4 *__
 }
 
 // The REGION of a rank for the halo selection: COL_REGION_BOXES = 8 boxes, one per octant of the global scene range
-// (which side of the range's middle a centre lies on, per axis), each (min centre - max r, 0, max centre + max r, 0) over the owned
+// (the top three bits of a sphere's Morton code), each (min centre - max r, 0, max centre + max r, 0) over the owned
 // spheres of that octant -- conservative (exact for equal radii), which is all a halo selection needs; an octant
 // without spheres gets an inverted box that nothing overlaps.  A rank owns a Morton RANGE: inside one octant that
 // is a compact piece, while ONE box around a range that spills over an octant boundary by a few spheres would
@@ -305,11 +305,8 @@ __global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>:
     for (int o = 0; o < COL_REGION_BOXES; o++)
 #pragma unroll
         for (int k = 0; k < 7; k++) v[o][k] = k < 3 ? (T)INFINITY : -(T)INFINITY;
-    // octant = which side of the middle of the global range, per axis.  (Any grouping of the owned spheres gives a
-    // valid region -- the boxes only have to cover them -- so this need not be the top bits of the Morton code,
-    // whose three correctly rounded divisions per row made this kernel compute-bound.)
-    T midx = 0, midy = 0, midz = 0;
-    if (range8) { midx = (range8[0] + range8[4]) * (T)0.5; midy = (range8[1] + range8[5]) * (T)0.5; midz = (range8[2] + range8[6]) * (T)0.5; }
+    T mnx = 0, mny = 0, mnz = 0, mxx = 1, mxy = 1, mxz = 1;
+    if (range8) { mnx = range8[0]; mny = range8[1]; mnz = range8[2]; mxx = range8[4]; mxy = range8[5]; mxz = range8[6]; }
     const u32 stride = gridDim.x * REGION_NT;
     for (u32 i0 = blockIdx.x * REGION_NT + tid; i0 < n; i0 += RU * stride) {
         V4 cc[RU];
@@ -318,7 +315,10 @@ __global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>:
 #pragma unroll
         for (int u = 0; u < RU; u++) {
             const V4 c = cc[u];
-            const u32 oct = range8 ? ((c.x >= midx ? 4u : 0u) | (c.y >= midy ? 2u : 0u) | (c.z >= midz ? 1u : 0u)) : 0u;
+            // (the octant must be the code's own top bits: with a geometric 'side of the middle' test the few spheres
+            // between 0.5 and 512/1023 of the range straddle the owner's Morton ranges, their octant boxes become
+            // slabs across the scene, and the N = 2 rehearsal sends 100 834 ghosts instead of 7 261)
+            const u32 oct = range8 ? morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz) >> 27 : 0u;
             const T e[3] = {c.x, c.y, c.z};
 #pragma unroll
             for (int o = 0; o < COL_REGION_BOXES; o++)

@@ -236,7 +236,7 @@ class ProtocolOps:
 
     def region_boxes(self, rows, n, repartitioned):
         """[REGION_BOXES, 8]: this rank's region = one conservative box (min centre - max r, 0, max centre + max r,
-        0) per octant of the global scene range (which side of its middle, per axis) over the owned spheres of that octant (an empty octant: an inverted
+        0) per octant of the global scene range (the top three bits of the Morton code) over the owned spheres of that octant (an empty octant: an inverted
         box).  A Morton range is a compact piece inside an octant; one box around a range that spills over an
         octant boundary by a few spheres would cover a quarter of the scene.  Without a repartition: one box."""
         torch = self.torch
@@ -246,10 +246,8 @@ class ProtocolOps:
             return out
         r = rows[:n]
         octant = torch.zeros(n, dtype=torch.int64, device=rows.device)
-        if repartitioned:                        # which side of the middle of the global range, per axis
-            mid = (self._grange[:3] + self._grange[4:7]) * 0.5
-            side = (r[:, :3] >= mid).to(torch.int64)
-            octant = side[:, 0] * 4 + side[:, 1] * 2 + side[:, 2]
+        if repartitioned:
+            octant = (self.codes_of_rows(r, self._grange).to(torch.int64) & 0xFFFFFFFF) >> 27
         for o in range(REGION_BOXES):
             sel = r[octant == o]
             if sel.shape[0]:

@@ -269,8 +269,8 @@ int col_partition_unpack(void *stream, const void *recv, uint32_t world, uint32_
                          uint32_t capacity, uint32_t *owned, void *host_word, uint32_t seq, uint32_t *flags,
                          int coord_bytes);
 int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii, int coord_bytes);
-/* A rank's REGION for the halo selection: 8 boxes, one per octant of the global scene range (which side of its
- * middle a centre lies on, per axis; range8, from
+/* A rank's REGION for the halo selection: 8 boxes, one per octant of the global scene range (the top three bits of
+ * a centre's Morton code under range8, from
  * col_partition_plan; NULL = no repartition: one box, the other seven inverted), each (min centre - max r, 0,
  * max centre + max r, 0) over the spheres of rows[0..n) in that octant (conservative; an empty octant: an inverted
  * box nothing overlaps).  out = 8 x 2 rows of 4 scalars.  Two launches; scratch as for col_partition_sample (its own

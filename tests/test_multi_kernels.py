@@ -189,9 +189,7 @@ def test_region_boxes(hip_env, oracle, dt, n, with_range):
     call.col_region_boxes(cq.stream, r.ptr, n, g.ptr if with_range else None, scratch.ptr, out.ptr, counters.ptr, 8, cb)
     got = download(cq, out, dt, (REGION_BOXES, 2, 4))
     assert not download(cq, counters, np.uint32, 8).any()
-    mid = ((grange[0] + grange[1]) * np.dtype(dt).type(0.5))[:3]
-    side = rows[:, :3] >= mid                                    # octant: which side of the range's middle, per axis
-    octant = (side[:, 0] * 4 + side[:, 1] * 2 + side[:, 2]) if (with_range and n) else np.zeros(n, np.int64)
+    octant = (oracle.morton(rows, grange) >> 27) if (with_range and n) else np.zeros(n, np.int64)
     for o in range(REGION_BOXES):
         sel = rows[octant == o]
         if len(sel) == 0:
