@@ -732,7 +732,19 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
                      uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
                      uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,
                      int sort_plan, uint32_t *oversize) {
+    return col_collide_plan_partials(stream, coords, radii, n, padded, coord_bytes, codes0, codes1, ids0, ids1, nodes, bounds,
+                                     flags, scratch, counter, pairs, capacity, sort_plan, oversize, nullptr, 0);
+}
+
+// col_collide_plan with the bounds partials of `coords` already computed (col_minmax4_stage1 / _dev: `parts` records of
+// [min row, max row] at `partials`; NULL = compute them here).  Used where the fused front end applies (below 16 Mi
+// spheres); above it the partials are ignored.
+int col_collide_plan_partials(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
+                              uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
+                              uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,
+                              int sort_plan, uint32_t *oversize, const void *partials, uint32_t parts) {
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
+    if (partials && (parts == 0 || parts > COL_MINMAX_PARTS)) return COL_EINVAL;
     if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     // a forced radix tile class (diagnostics) would not match the histogram the fused Morton kernel writes
@@ -758,10 +770,12 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
         // Up to 16 Mi spheres the front end is fused: the Morton kernel folds the bounds partials itself and
         // counts the digits of the sort's first pass (the histogram sits at the start of the sort scratch): two
         // launches less.  The MSD plan (one global pass + an LDS finish per bucket) applies up to COL_MSD_MAX_N.
-        uint32_t parts = 0;
         const bool msd = sort_plan == COL_SORT_MSD && padded <= COL_MSD_MAX_N;
-        if ((rc = col_minmax4_stage1(stream, coords, n, coord_bytes, red_scratch, &parts))) return rc;
-        if ((rc = col_morton_tile(stream, coords, radii, red_scratch, parts, n, padded, coord_bytes, codes0, ids0, packed,
+        if (!partials) {
+            if ((rc = col_minmax4_stage1(stream, coords, n, coord_bytes, red_scratch, &parts))) return rc;
+            partials = red_scratch;
+        }
+        if ((rc = col_morton_tile(stream, coords, radii, partials, parts, n, padded, coord_bytes, codes0, ids0, packed,
                                   counter, (uint32_t *)sort_scratch, tile, (uint32_t)col_ceil_div(padded, tile), msd ? 22 : 0))) return rc;
         if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);

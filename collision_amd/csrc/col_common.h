@@ -42,6 +42,8 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 #define COL_MSD_SMALL_N 1900000u
 #define COL_MSD_MAX_N 4050000u
 extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
+extern "C" int col_minmax4_stage1_dev(void *stream, const void *rows, const uint32_t *n_dev, uint32_t n_max, int coord_bytes,
+                                      void *partials, uint32_t *parts);
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
                                uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift);

@@ -106,6 +106,24 @@ __global__ __launch_bounds__(RT) void k_reduce1(const Row<T, W> *__restrict__ ro
     block_fold<T, W, OP>(acc, partials + (size_t)blockIdx.x * Acc<T, W, OP>::N);
 }
 
+// k_reduce1 for [min row, max row] of 4-wide rows with the row count read from DEVICE memory (clamped to n_max): the
+// multi-GPU path enqueues it right behind the launch that produces the count, before the host knows it (multi.py)
+template <typename T>
+__global__ __launch_bounds__(RT) void k_minmax4_dev(const Row<T, 4> *__restrict__ rows, const u32 *__restrict__ n_dev, u32 n_max,
+                                                    T *partials) {
+    Acc<T, 4, COL_OP_MINMAX> acc;
+    acc.init();
+    const uint64_t n = min(*n_dev, n_max);
+    const uint64_t stride = (uint64_t)gridDim.x * RT;
+    uint64_t i = (uint64_t)blockIdx.x * RT + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        Row<T, 4> r0 = rows[i], r1 = rows[i + stride], r2 = rows[i + 2 * stride], r3 = rows[i + 3 * stride];
+        acc.add_row(r0); acc.add_row(r1); acc.add_row(r2); acc.add_row(r3);
+    }
+    for (; i < n; i += stride) acc.add_row(rows[i]);
+    block_fold<T, 4, COL_OP_MINMAX>(acc, partials + (size_t)blockIdx.x * Acc<T, 4, COL_OP_MINMAX>::N);
+}
+
 template <typename T, int W, int OP>
 __global__ __launch_bounds__(RT) void k_reduce2(const T *partials, uint32_t nparts, T *out) {
     constexpr int N = Acc<T, W, OP>::N;
@@ -264,6 +282,26 @@ int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_byt
     else if (coord_bytes == 8)
         k_reduce1<double, 4, COL_OP_MINMAX><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>(
             (const Row<double, 4> *)rows, n, (double *)partials);
+    else
+        return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+// The same partials with the row count in device memory (*n_dev, at most n_max): the grid is sized for n_max, blocks
+// without rows leave the identity, and min / max being exact and order-independent the fold gives the bits of
+// col_minmax4_stage1 on the true count.
+int col_minmax4_stage1_dev(void *stream, const void *rows, const uint32_t *n_dev, uint32_t n_max, int coord_bytes, void *partials,
+                           uint32_t *parts) {
+    if (!n_dev || !partials || !parts) return COL_EINVAL;
+    uint64_t blocks = col_ceil_div(n_max, (uint64_t)RT * 16);
+    if (blocks > COL_MINMAX_PARTS) blocks = COL_MINMAX_PARTS;
+    if (blocks == 0) blocks = 1;
+    *parts = (uint32_t)blocks;
+    if (coord_bytes == 4)
+        k_minmax4_dev<float><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>((const Row<float, 4> *)rows, n_dev, n_max, (float *)partials);
+    else if (coord_bytes == 8)
+        k_minmax4_dev<double><<<dim3((unsigned)blocks), dim3(RT), 0, col_stream(stream)>>>((const Row<double, 4> *)rows, n_dev, n_max, (double *)partials);
     else
         return COL_EINVAL;
     COL_LAUNCH_OK();

@@ -41,6 +41,7 @@ the distributed protocol itself only needs ``torch.distributed`` and tensors on 
 so the world_size-2..8 ``gloo`` tests drive it on the CPU with a test double for the engine.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -93,37 +94,41 @@ class Exchange:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.nccl = dist.get_backend() == "nccl"
         self.stage = not self.nccl and device.type != "cpu"
+        self._gathered = {}              # all-gather outputs by input buffer (nccl)
+        self._a2a_views = {}             # (send view, recv view, split lists) by buffers and counts (nccl)
 
     def all_gather(self, t):
-        """[...] -> [world, ...]"""
-        return self.all_gather_finish(self.all_gather_start(t))
-
-    def all_gather_start(self, t):
-        """Enqueue the all-gather; with RCCL the current stream does NOT wait for it until
-        all_gather_finish, so kernels launched in between overlap it."""
+        """[...] -> [world, ...].  With RCCL a synchronous op: it is enqueued on the CURRENT stream (no hand-off to the
+        process group's own stream and back: two cross-stream event waits of 10-15 us each per collective on this
+        platform).  The output tensor of a given input buffer is kept (the host side of a step is nearly as long as
+        its device side at 1 M spheres: every allocation counts)."""
         torch = self.torch
         if self.nccl:
-            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            return out, self.dist.all_gather_into_tensor(out, t.contiguous(), async_op=True)
+            key = (t.data_ptr(), tuple(t.shape), t.dtype)
+            out = self._gathered.get(key)
+            if out is None:
+                out = self._gathered[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t)
+            return out
         src = t.cpu() if self.stage else t.contiguous()
         out = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(out, src)
-        return torch.stack(out).to(self.device), None
-
-    def all_gather_finish(self, started):
-        out, work = started
-        if work is not None:
-            work.wait()                       # the current stream waits for the collective (no host sync)
-        return out
+        return torch.stack(out).to(self.device)
 
     def all_to_all_v(self, send, send_counts, recv, recv_counts):
         """Rows grouped by destination in `send`, received grouped by source into `recv`; the counts
         (rows per rank) are host lists."""
         torch, dist = self.torch, self.dist
-        ns, nr = sum(send_counts), sum(recv_counts)
         if self.nccl:
-            dist.all_to_all_single(recv[:nr], send[:ns], list(recv_counts), list(send_counts))
+            key = (send.data_ptr(), recv.data_ptr(), tuple(send_counts), tuple(recv_counts))
+            v = self._a2a_views.get(key)
+            if v is None:
+                if len(self._a2a_views) > 64:
+                    self._a2a_views.clear()
+                v = self._a2a_views[key] = (recv[:sum(recv_counts)], send[:sum(send_counts)], list(recv_counts), list(send_counts))
+            dist.all_to_all_single(*v)
             return
+        ns, nr = sum(send_counts), sum(recv_counts)
         s = send[:ns].cpu() if self.stage else send[:ns]
         r = torch.empty((nr,) + tuple(send.shape[1:]), dtype=send.dtype)
         so = np.concatenate([[0], np.cumsum(send_counts)]).astype(int)
@@ -319,6 +324,10 @@ class HipEngine(ProtocolOps):
         nscratch = call.col_partition_scratch_bytes()
         self._range_scratch = torch.zeros(nscratch, dtype=torch.uint8, device=dev)        # main stream
         self._range_scratch_side = torch.zeros(nscratch, dtype=torch.uint8, device=dev)   # halo branch
+        self._bounds_partials = torch.zeros(256 * 8 * self.cb, dtype=torch.uint8, device=dev)     # col_minmax4_stage1_dev
+        self._bounds_parts = C.c_uint32(0)
+        self._have_partials = False
+        self._early_partials = not os.environ.get("COLLISION_NO_EARLY_PARTIALS")
         word = C.c_void_p()
         call.col_host_alloc(C.byref(word), 64)
         self._host_word = word.value                           # host-visible: (step number << 32 | owned count)
@@ -331,7 +340,7 @@ class HipEngine(ProtocolOps):
         self._p = {k: getattr(self, k).data_ptr() for k in
                    ("rows_in", "gids_in", "dest", "owners_sorted", "perm", "iota", "hist", "owned_rows", "owned_gids",
                     "radii", "sel_lists", "sel_counts", "pairs", "counter", "flags", "owned2", "payload", "grange8",
-                    "boxes", "split", "owner_counts", "_range_scratch", "_range_scratch_side")}
+                    "boxes", "split", "owner_counts", "_range_scratch", "_range_scratch_side", "_bounds_partials")}
 
     def __del__(self):
         word, self._host_word = getattr(self, "_host_word", None), None
@@ -404,7 +413,13 @@ class HipEngine(ProtocolOps):
         call.col_partition_unpack(self.cq.stream, self.part_recv.data_ptr(), world, rank, slot, p["owner_counts"],
                                   p["owned_rows"], p["owned_gids"], p["radii"], self.capacity, p["owned2"],
                                   self._host_word, self._seq, p["flags"], self.cb)
+        # the first launch of the local pipeline (block partials of the scene bounds) does not need m on the host: it
+        # reads the owned count from the device, so the device is busy while the host polls and enqueues the rest
         self._owned_event.record(self.main)
+        if self._early_partials:
+            call.col_minmax4_stage1_dev(self.cq.stream, p["owned_rows"], p["owned2"], self.capacity, self.cb,
+                                        p["_bounds_partials"], C.byref(self._bounds_parts))
+            self._have_partials = True
 
     def owned_count(self):
         """The step's one host wait: the unpack launch writes (step number << 32 | m) into a host-visible word."""
@@ -436,10 +451,13 @@ class HipEngine(ProtocolOps):
         c, p = self.collider, self._p
         if rows is not self.owned_rows:           # owned rows come out of the repartition with radii already split off
             call.col_unpack_radii(s, rows.data_ptr(), n, p["radii"], self.cb)
-        call.col_collide_plan(s, rows.data_ptr(), p["radii"], n, roundUp(n, 2 * self.group_size), self.cb,
-                              c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
-                              c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
-                              p["counter"], p["pairs"], self.pair_capacity, c._choose_sort_plan(), c._plan_word)
+        partials = p["_bounds_partials"] if (rows is self.owned_rows and self._have_partials) else None
+        self._have_partials = False
+        call.col_collide_plan_partials(s, rows.data_ptr(), p["radii"], n, roundUp(n, 2 * self.group_size), self.cb,
+                                       c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
+                                       c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
+                                       p["counter"], p["pairs"], self.pair_capacity, c._choose_sort_plan(), c._plan_word,
+                                       partials, self._bounds_parts.value if partials else 0)
         call.col_translate_pairs(s, p["pairs"], p["counter"], 0, self.pair_capacity, gids.data_ptr())
 
     # -- halo branch (side stream)
@@ -537,6 +555,7 @@ class DistributedCollider:
         if partition_slot is not None:
             self.part_slot = int(partition_slot)
         self.repeats = 0                         # steps repeated because a slot overflowed
+        self._splits, self._halo_splits = {}, {}
         self._dirty = False
         self.own_rows = self.own_gids = None
         self.n_owned = 0
@@ -572,7 +591,9 @@ class DistributedCollider:
             e.ensure_partition_slots(pslot, R)
             e.partition_plan(gathered, rows, n, R)
             e.partition_group(rows, gids, n, R, r, pslot)
-            split = [pslot + 1 if q != r else 0 for q in range(R)]
+            split = self._splits.get(pslot)
+            if split is None:
+                split = self._splits[pslot] = tuple(pslot + 1 if q != r else 0 for q in range(R))
             x.all_to_all_v(e.part_send, split, e.part_recv, split)
             e.partition_unpack(R, r, pslot)
             e.mark_fork()
@@ -598,9 +619,11 @@ class DistributedCollider:
             with e.halo_stream():
                 boxes = x.all_gather(e.region_boxes(own_rows, m, repartition))   # [R, 8 boxes, 8], stays on the device
                 e.select_and_pack(own_rows, own_gids, m, boxes, self.peers_out, slot)
-                out_rows = [slot + 1 if q in self.peers_out else 0 for q in range(R)]
-                in_rows = [slot + 1 if q in self.peers_in else 0 for q in range(R)]
-                x.all_to_all_v(e.halo_send, out_rows, e.halo_recv, in_rows)
+                rows_io = self._halo_splits.get(slot)
+                if rows_io is None:
+                    rows_io = self._halo_splits[slot] = (tuple(slot + 1 if q in self.peers_out else 0 for q in range(R)),
+                                                         tuple(slot + 1 if q in self.peers_in else 0 for q in range(R)))
+                x.all_to_all_v(e.halo_send, rows_io[0], e.halo_recv, rows_io[1])
             # 4. ghosts as queries against my tree (slot lengths are read from the headers on the device)
             e.join()
             e.ghost_queries(len(self.peers_in), slot, own_gids)

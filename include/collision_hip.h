@@ -230,6 +230,19 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
                      int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
                      col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,
                      uint32_t *collisions, uint32_t capacity, int sort_plan, uint32_t *oversize);
+/* The same call with the first launch of the path -- the block partials of the scene bounds, [min row, max row] of
+ * `coords` -- already made: col_minmax4_stage1_dev computes them with the row count read from DEVICE memory
+ * (*n_dev, at most n_max; `partials` = 256 records of 8 scalars, *parts = the number written), so it can be enqueued
+ * before the host knows the count (the multi-GPU step: right behind col_partition_unpack, while the host still polls
+ * for the owned count; the device then has work when the rest of the path arrives).  partials == NULL: as
+ * col_collide_plan.  Above 16 Mi spheres (no fused front end) the partials are ignored. */
+int col_minmax4_stage1_dev(void *stream, const void *rows, const uint32_t *n_dev, uint32_t n_max, int coord_bytes,
+                           void *partials, uint32_t *parts);
+int col_collide_plan_partials(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded_size,
+                              int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
+                              col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,
+                              uint32_t *collisions, uint32_t capacity, int sort_plan, uint32_t *oversize,
+                              const void *partials, uint32_t parts);
 
 /* ---------------------------------------------------------------- multi-GPU helpers
  * New work (the reference is single-device): device side of the sphere

@@ -22,10 +22,23 @@ for partition, exercise in configs:
     for _ in range(5):
         dc.step()
     dc.synchronize()
+    waited = [0.0]
+    inner = dc.engine.owned_count
+    def timed_owned_count():
+        t = time.perf_counter()
+        m = inner()
+        waited[0] += time.perf_counter() - t
+        return m
+    dc.engine.owned_count = timed_owned_count
     t0 = time.perf_counter()
     for _ in range(30):
         dc.step()
+    host_ms = (time.perf_counter() - t0) / 30 * 1e3       # host time in step(): enqueueing + the poll
     dc.synchronize()
     ms = (time.perf_counter() - t0) / 30 * 1e3
-    print("partition=%s exchanges=%s: %.3f ms/step, %d pairs" % (partition, exercise, ms, dc.local_pair_count()))
+    print("   host: %.3f ms/step in step(), of which %.3f ms polling for the owned count" % (host_ms, waited[0] / 30 * 1e3))
+    c = dc.engine.collider
+    print("partition=%s exchanges=%s: %.3f ms/step, %d pairs   [repeats %d, slots %s/%s, lsd calls left %s, retry %s, oversize %s]" % (
+        partition, exercise, ms, dc.local_pair_count(), dc.repeats, dc.part_slot, dc.slot, getattr(c, "_lsd_calls_left", None),
+        getattr(c, "_retry_after", None), c.oversize_bucket))
 dist.destroy_process_group()
