@@ -12,14 +12,18 @@ from collision_amd import hip
 from collision_amd.multi import DistributedCollider
 import bench
 n = 1000000
+STEPS = 100
 coords, radii = bench.uniform_scene(n)
 configs = (("morton", False), ("morton", True), ("hash", True))
 if len(sys.argv) > 1:
     configs = ((sys.argv[1], True),)
+pads = []
 for partition, exercise in configs:
+    if os.environ.get("PAD_KB"):               # (experiment: shift every later allocation)
+        pads.append(torch.empty(int(os.environ["PAD_KB"]) * 1024, dtype=torch.uint8, device="cuda"))
     dc = DistributedCollider(hip.Context(0), dist, n, pair_capacity=1 << 19, partition=partition, exercise_single_rank=exercise)
     dc.set_local_spheres(coords, radii, np.arange(n, dtype=np.uint32))
-    for _ in range(5):
+    for _ in range(int(os.environ.get("WARM", "150"))):     # (long enough for GPU and host clocks)
         dc.step()
     dc.synchronize()
     waited = [0.0]
@@ -31,12 +35,12 @@ for partition, exercise in configs:
         return m
     dc.engine.owned_count = timed_owned_count
     t0 = time.perf_counter()
-    for _ in range(30):
+    for _ in range(STEPS):
         dc.step()
-    host_ms = (time.perf_counter() - t0) / 30 * 1e3       # host time in step(): enqueueing + the poll
+    host_ms = (time.perf_counter() - t0) / STEPS * 1e3       # host time in step(): enqueueing + the poll
     dc.synchronize()
-    ms = (time.perf_counter() - t0) / 30 * 1e3
-    print("   host: %.3f ms/step in step(), of which %.3f ms polling for the owned count" % (host_ms, waited[0] / 30 * 1e3))
+    ms = (time.perf_counter() - t0) / STEPS * 1e3
+    print("   host: %.3f ms/step in step(), of which %.3f ms polling for the owned count" % (host_ms, waited[0] / STEPS * 1e3))
     c = dc.engine.collider
     print("partition=%s exchanges=%s: %.3f ms/step, %d pairs   [repeats %d, slots %s/%s, lsd calls left %s, retry %s, oversize %s]" % (
         partition, exercise, ms, dc.local_pair_count(), dc.repeats, dc.part_slot, dc.slot, getattr(c, "_lsd_calls_left", None),
