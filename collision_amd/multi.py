@@ -279,7 +279,10 @@ class HipEngine(ProtocolOps):
         self.device = torch.device("cuda", ctx.device)
         torch.cuda.set_device(self.device)
         self.main = torch.cuda.current_stream()
-        self.side = torch.cuda.Stream()                       # the halo branch
+        # the halo branch.  A stream of the other priority class: torch hands out its pooled streams round-robin and
+        # HIP maps them onto a few hardware queues -- the first pooled stream of a process shared the queue of the
+        # current stream, and the branch then ran AFTER the local pipeline instead of beside it (+50 us per step)
+        self.side = torch.cuda.Stream(priority=-1)
         self.cq = hip.CommandQueue(ctx, stream=self.main.cuda_stream)
         self.cq_side = hip.CommandQueue(ctx, stream=self.side.cuda_stream)
         self.capacity, self.pair_capacity = capacity, pair_capacity
