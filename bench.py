@@ -352,6 +352,21 @@ def cpu_bruteforce_all_cores(n=100000):
             "extrapolated_seconds_at_1M": dt * (N_SPHERES / n) ** 2}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run as a
+    child process (never an exec: nothing here may replace a process that could hold the GPU) and return its
+    exit code.  The rendezvous is on 127.0.0.1 at a port that is free right now."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,9 +383,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # typed as a plain command: this process (which has not touched torch or HIP) starts the ranks itself,
+            # one per GPU, as a child torch.distributed.run; rank 0's JSON line goes straight to our stdout
+            sys.exit(launch_ranks(args.gpus))
         args.gpus = world
 
     dist = None

@@ -539,22 +539,28 @@ __global__ __launch_bounds__(1024) void k_owner_offsets(u32 *__restrict__ hist, 
 
 // After the stable grouping (position i holds sphere perm[i] of owner owners[i]): the spheres this rank keeps go
 // straight to the front of its owned arrays; the others into the slot of their owner -- a header record whose
-// first word is the full length of the list, then min(length, slot) transport records.  A list longer than the
-// slot is visible to both sides in the header and is reported in flags[2] (longest list seen).
+// first word is the full length of the list, then min(length, slot) transport records.  What does NOT fit into a
+// slot STAYS WITH THIS RANK: it is appended to the owned arrays behind the kept rows (owner order).  Which rank owns
+// a sphere is a matter of load balance and halo size only -- the halo selection works on what a rank really owns --
+// so a slot that is too small costs locality for one step and never a sphere; the header (and flags[2], longest
+// list seen) tells the host to grow the slots for the steps that follow.
 template <typename T>
 __global__ __launch_bounds__(256) void k_partition_pack(const typename MT<T>::V4 *__restrict__ rows, const u32 *__restrict__ gids,
                                                          const u32 *__restrict__ perm, const u32 *__restrict__ owners,
                                                          const u32 *__restrict__ counts, u32 n, u32 world, u32 rank, u32 slot,
-                                                         u32 *__restrict__ send, typename MT<T>::V4 *__restrict__ own_rows,
+                                                         u32 capacity, u32 *__restrict__ send, typename MT<T>::V4 *__restrict__ own_rows,
                                                          u32 *__restrict__ own_gids, T *__restrict__ own_radii,
                                                          u32 *__restrict__ flags) {
     constexpr int RW = MT<T>::RW;
     __shared__ u32 s_warp[4];
-    __shared__ u32 s_start[256];
+    __shared__ u32 s_start[256], s_stay[256];
     const u32 tid = threadIdx.x;
     const u32 cnt = tid < world ? counts[tid] : 0u;
     u32 total;
     s_start[tid] = block_excl_scan<256>(cnt, s_warp, &total);
+    // rows that stay here: all of this rank's own list, and the part of every other list beyond the slot
+    const u32 stay = tid == rank ? cnt : (cnt > slot ? cnt - slot : 0u);
+    s_stay[tid] = block_excl_scan<256>(stay, s_warp, &total);
     __syncthreads();
     if (blockIdx.x == 0 && tid < world && tid != rank) {
         u32 *hdr = send + (u64)RW * (tid < rank ? tid : tid - 1) * (slot + 1);
@@ -566,18 +572,24 @@ __global__ __launch_bounds__(256) void k_partition_pack(const typename MT<T>::V4
     const u32 q = owners[i], pos = i - s_start[q], src = perm[i];
     const typename MT<T>::V4 c = rows[src];
     const u32 gid = gids[src];
-    if (q == rank) {
-        own_rows[pos] = c;
-        own_gids[pos] = gid;
-        own_radii[pos] = c.w;
-    } else if (pos < slot)
+    if (q != rank && pos < slot) {
         rec_store<T>(send + (u64)RW * ((u64)(q < rank ? q : q - 1) * (slot + 1) + 1 + pos), c, gid);
+        return;
+    }
+    // kept rows first (this rank's own list), then the overflow of the other lists in owner order
+    const u32 kept = counts[rank];
+    const u32 before = s_stay[q] - (q > rank ? kept : 0u);      // overflow rows of owners below q
+    const u64 dst = q == rank ? (u64)pos : (u64)kept + before + (pos - slot);
+    if (dst >= capacity) return;                                 // (the unpack reports m > capacity)
+    own_rows[dst] = c;
+    own_gids[dst] = gid;
+    own_radii[dst] = c.w;
 }
 
 // Received slots (blockIdx.y = slot of the k-th other rank, in rank order) -> the owned arrays, behind the
-// spheres the rank kept; block (0, 0) publishes the owned count: owned[0] = min(m, capacity), owned[1] = m, and
-// (sequence number << 32 | m) into a host-visible word, which is all the host waits for before it sizes the
-// local pipeline.
+// spheres the rank kept (its own list and the overflow of the lists it sent, k_partition_pack); block (0, 0)
+// publishes the owned count: owned[0] = min(m, capacity), owned[1] = m, and (sequence number << 32 | m) into a
+// host-visible word, which is all the host waits for before it sizes the local pipeline.
 template <typename T>
 __global__ __launch_bounds__(256) void k_partition_unpack(const u32 *__restrict__ recv, u32 world, u32 rank, u32 slot,
                                                            const u32 *__restrict__ counts, typename MT<T>::V4 *__restrict__ own_rows,
@@ -592,12 +604,14 @@ __global__ __launch_bounds__(256) void k_partition_unpack(const u32 *__restrict_
     u32 total;
     s_off[tid] = block_excl_scan<256>(min(len, slot), s_warp, &total);
     s_len[tid] = len;
+    const u32 mine = tid < world ? counts[tid] : 0u;
+    u32 stayed;                                  // rows already in the owned arrays: kept + overflow of the sent lists
+    block_excl_scan<256>(tid == rank ? mine : (mine > slot ? mine - slot : 0u), s_warp, &stayed);
     __syncthreads();
-    const u32 kept = counts[rank];
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (tid < others && len) atomicMax(&flags[2], len);
         if (tid == 0) {
-            const u64 m = (u64)kept + total;
+            const u64 m = (u64)stayed + total;
             owned[0] = (u32)(m < capacity ? m : capacity);
             owned[1] = (u32)(m < 0xFFFFFFFFull ? m : 0xFFFFFFFFull);
             if (host_word)
@@ -608,7 +622,7 @@ __global__ __launch_bounds__(256) void k_partition_unpack(const u32 *__restrict_
     const u32 k = blockIdx.y, cnt = min(s_len[k], slot);
     const u32 *base = recv + (u64)RW * ((u64)k * (slot + 1) + 1);
     for (u32 i = blockIdx.x * 256 + tid; i < cnt; i += gridDim.x * 256) {
-        const u64 dst = (u64)kept + s_off[k] + i;
+        const u64 dst = (u64)stayed + s_off[k] + i;
         if (dst >= capacity) break;
         u32 gid;
         const typename MT<T>::V4 c = rec_load<T>(base + (u64)RW * i, &gid);
@@ -695,11 +709,12 @@ int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint3
 }
 
 // iota: 0, 1, 2, ... (n words); owners_sorted / perm: n words each.  send: (world - 1) slots of (slot + 1)
-// transport records, in rank order without this rank.  flags[2] = max(flags[2], longest list sent).
+// transport records, in rank order without this rank; own_*: `capacity` rows (kept rows, then what did not fit
+// into the slots).  flags[2] = max(flags[2], longest list).
 int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
                         const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world, uint32_t rank,
                         uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows, uint32_t *own_gids,
-                        void *own_radii, uint32_t *flags, int coord_bytes) {
+                        void *own_radii, uint32_t capacity, uint32_t *flags, int coord_bytes) {
     if (world == 0 || world > 256 || rank >= world || slot == 0 || !flags) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
@@ -708,8 +723,8 @@ int col_partition_group(void *stream, const void *rows, const uint32_t *gids, ui
         if (rc) return rc;
     }
     const unsigned g = n ? blocks_for(n) : 1u;          // (an empty rank still writes its slot headers)
-    COL_BY_COORD((k_partition_pack<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, (u32 *)send, (float4 *)own_rows, own_gids, (float *)own_radii, flags)),
-                 (k_partition_pack<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, (u32 *)send, (double4 *)own_rows, own_gids, (double *)own_radii, flags)));
+    COL_BY_COORD((k_partition_pack<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, capacity, (u32 *)send, (float4 *)own_rows, own_gids, (float *)own_radii, flags)),
+                 (k_partition_pack<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, capacity, (u32 *)send, (double4 *)own_rows, own_gids, (double *)own_radii, flags)));
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -28,9 +28,15 @@ New work -- the reference is single-device.  Spheres arri
 4. **Ghost queries**: received spheres are QUERIES against the local tree (never inserted) and emit
    ``(ghost id, local id)`` pairs; the kernel reads the slot lengths from the headers.
 
-A slot (repartition or halo) that is too small for its list is detected from its header (``synchronize``
-reads the flags): the slot size is then raised on every rank and the step repeated, so results read after
-``synchronize`` are always exact.  ``synchronize`` also lets the slot sizes follow the longest lists seen.
+A HALO slot that is too small for its list is detected from its header (``synchronize`` reads the flags): the
+slot size is then raised on every rank and the step repeated, so results read after ``synchronize`` are always
+exact.  A REPARTITION slot that is too small loses nothing: what does not fit stays with the sending rank (which
+rank owns a sphere only decides load balance and halo size, never the pair set), so ``adopt_owned`` is safe
+without a host check; ``synchronize`` lets both slot sizes follow the longest lists seen.
+
+The protocol is written once, as a generator that yields at each collective (``_step_gen``): ``step()`` drives
+it with the rank's ``Exchange`` (torch.distributed); ``LoopbackWorld`` drives the generators of R ranks that live
+in ONE process in lockstep and copies between their buffers -- config 4's eight ranks on a one-GPU box.
 
 A cross-rank pair {a in r, b in q} is reported by exactly one side: rank r answers the ghosts of
 rank q iff ``handles(r, q, R)``.  The union over ranks of the unordered id pairs equals the
@@ -205,26 +211,35 @@ class ProtocolOps:
             self.part_send, self.part_recv = self._recs(want), self._recs(want)
 
     def partition_group(self, rows, gids, n, world, rank, slot):
-        """Stable grouping by owner; kept rows to the front of the owned arrays, the others into their slots."""
+        """Stable grouping by owner; kept rows to the front of the owned arrays, the others into their slots; what
+        does not fit into a slot stays here, behind the kept rows (owner order)."""
         torch = self.torch
         perm = torch.sort(self._dest, stable=True).indices
         starts = [0] + [int(v) for v in torch.cumsum(self._owner_counts, 0).tolist()]
+        off = starts[rank + 1] - starts[rank]
+        idx = perm[starts[rank]:starts[rank + 1]]
+        self.owned_rows[:off] = rows[idx]
+        self.owned_gids[:off] = gids[idx]
         for q in range(world):
+            if q == rank:
+                continue
             idx = perm[starts[q]:starts[q + 1]]
             cnt = int(idx.numel())
-            if q == rank:
-                self.owned_rows[:cnt] = rows[idx]
-                self.owned_gids[:cnt] = gids[idx]
-                self._kept = cnt
-                continue
             base = (q if q < rank else q - 1) * (slot + 1)
             self.part_send[base] = 0
             self.part_send[base, 0] = cnt
             self._longest_part = max(self._longest_part, cnt)
             self.pack5(rows, gids, idx.to(torch.int32), 0, min(cnt, slot), self.part_send, base + 1)
+            if cnt > slot:
+                extra = idx[slot:][:max(0, self.capacity - off)]
+                k = int(extra.numel())
+                self.owned_rows[off:off + k] = rows[extra]
+                self.owned_gids[off:off + k] = gids[extra]
+                off += cnt - slot
+        self._kept = off
 
     def partition_unpack(self, world, rank, slot):
-        """Received slots, in rank order, behind the kept rows; the owned count m."""
+        """Received slots, in rank order, behind the rows that stayed; the owned count m."""
         off = self._kept
         for k in range(world - 1):
             base = k * (slot + 1)
@@ -407,8 +422,8 @@ class HipEngine(ProtocolOps):
         p = self._p
         call.col_partition_group(self.cq.stream, rows.data_ptr(), gids.data_ptr(), n, p["dest"], p["iota"], p["hist"],
                                  p["owner_counts"], world, rank, slot, p["owners_sorted"], p["perm"],
-                                 self.part_send.data_ptr(), p["owned_rows"], p["owned_gids"], p["radii"], p["flags"],
-                                 self.cb)
+                                 self.part_send.data_ptr(), p["owned_rows"], p["owned_gids"], p["radii"], self.capacity,
+                                 p["flags"], self.cb)
 
     def partition_unpack(self, world, rank, slot):
         p = self._p
@@ -520,21 +535,55 @@ class HipEngine(ProtocolOps):
 
 
 # --------------------------------------------------------------------------- the protocol
+def _agree_max(dist, values, ctx):
+    """Element-wise maximum of a few host integers over all ranks (sizes every rank must agree on)."""
+    import torch
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", ctx.device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.cpu().tolist()]
+
+
 class DistributedCollider:
+    """One rank of the multi-GPU broad phase.
+
+    ``n_local`` may differ from rank to rank (a hash partition is balanced to +-0.1 % only); every buffer size of the
+    fixed-size exchanges -- rank capacity, halo slot, repartition slot -- is derived from the MAXIMUM over the ranks,
+    agreed by one all-reduce in the constructor (``n_agreed`` skips it: the caller already knows the maximum).
+    ``engine`` is a device engine, or a callable ``capacity -> engine`` (the CPU test double), or None (HipEngine).
+    ``exchange`` replaces the torch.distributed ``Exchange`` (LoopbackWorld: several ranks in one process)."""
+
+    MIN_PARTITION_SLOT = 1024      # records; synchronize() never shrinks a repartition slot below this
+
     def __init__(self, ctx, dist, n_local, group_size=256, pair_capacity=1 << 19, partition="morton",
                  slack=1.6, engine=None, exercise_single_rank=False, halo_slot=None, coord_dtype=np.dtype("float32"),
-                 partition_slot=None):
+                 partition_slot=None, exchange=None, n_agreed=None):
         if partition not in ("morton", "hash"):
             raise ValueError("partition must be 'morton' or 'hash'")
         self.dist, self.partition = dist, partition
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        capacity = roundUp(int(n_local * slack) + 4096, 2 * group_size)
+        if exchange is not None:
+            self.rank, self.world = exchange.rank, exchange.world
+            if n_agreed is None:
+                raise ValueError("an external exchange needs n_agreed (the largest n_local of all ranks)")
+        else:
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if n_agreed is None:
+            n_agreed = _agree_max(dist, [n_local], ctx)[0] if self.world > 1 else int(n_local)
+        if n_local > n_agreed:
+            raise ValueError("n_local %d > the agreed maximum %d" % (n_local, n_agreed))
+        self.n_agreed = n_agreed = int(n_agreed)
+        capacity = roundUp(int(n_agreed * slack) + 4096, 2 * group_size)
+        if callable(engine):
+            engine = engine(capacity)
         self.engine = engine or HipEngine(ctx, capacity, group_size, pair_capacity, coord_dtype)
+        if self.engine.capacity != capacity:
+            raise ValueError("engine capacity %d != the agreed rank capacity %d" % (self.engine.capacity, capacity))
         self.capacity = capacity
-        self.x = Exchange(dist, self.engine.device)
+        self.x = exchange if exchange is not None else Exchange(dist, self.engine.device)
         self.cq = getattr(self.engine, "cq", None)
         self.n_in = 0
-        self.stats = {}
+        self.stats = {"partition_overflows": 0}
         # run every exchange even when world_size == 1 (each collective then talks to itself): lets a
         # one-GPU box drive the real RCCL code paths
         self.exercise = exercise_single_rank
@@ -554,10 +603,10 @@ class DistributedCollider:
         # records per repartition slot (one per other rank): spheres that arrive hash-partitioned leave for every
         # rank in equal shares; synchronize() follows the longest list seen (a spatially coherent arrival
         # sends little, and what a rank keeps does not travel at all)
-        self.part_slot = max(1024, roundUp(int(1.3 * n_local / R) + 1024, 1024)) if R > 1 else 1024
+        self.part_slot = max(1024, roundUp(int(1.3 * n_agreed / R) + 1024, 1024)) if R > 1 else 1024
         if partition_slot is not None:
             self.part_slot = int(partition_slot)
-        self.repeats = 0                         # steps repeated because a slot overflowed
+        self.repeats = 0                         # steps repeated because a halo slot overflowed
         self._splits, self._halo_splits = {}, {}
         self._dirty = False
         self.own_rows = self.own_gids = None
@@ -568,18 +617,54 @@ class DistributedCollider:
 
     def adopt_owned(self):
         """What this rank owns after the last step() becomes its input for the next one: a simulation that advances
-        positions where the spheres live.  Nothing is copied (the engine swaps its input and owned arrays, in stream
-        order) and nothing waits.  Spheres that have not moved far stay with their rank: they are 'kept' by the next
-        repartition and never travel, and synchronize() lets the repartition slots shrink to what still moves."""
+        positions where the spheres live (``local_rows()`` / ``local_gids()`` are the arrays to advance).  Nothing is
+        copied (the engine swaps its input and owned arrays, in stream order) and nothing waits.  Safe without looking
+        at the last step's flags: a repartition slot that was too small left its surplus with the sender, so the
+        owned sets of all ranks are always a partition of the scene; a halo slot that was too small only affects the
+        pairs of that step, which synchronize() repairs by repeating it on the (identical) adopted input.
+        Spheres that have not moved far stay with their rank: they are 'kept' by the next repartition and never
+        travel, and synchronize() lets the repartition slots shrink to what still moves."""
         if self.own_rows is None or self.own_rows is self.engine.rows_in:
             return                            # (no repartition ran: the input already is what the rank owns)
         self.engine.swap_input_and_owned()
         self.n_in = self.n_owned
         self.own_rows, self.own_gids = self.engine.rows_in, self.engine.gids_in
 
+    def local_rows(self):
+        """[n_in, 4] (x, y, z, r) rows of the next step's input, on the engine's device (a view: advance in place)."""
+        return self.engine.rows_in[:self.n_in]
+
+    def local_gids(self):
+        """[n_in] global ids (int32 bit patterns of uint32) of the next step's input."""
+        return self.engine.gids_in[:self.n_in]
+
     # -- one step ------------------------------------------------------------------------------
+    def _drive(self, gen):
+        """Run a protocol generator against this rank's Exchange: every yield is (collective, stream, args...)."""
+        x, e = self.x, self.engine
+        side, reply = None, None
+        try:
+            while True:
+                req = gen.send(reply)
+                if req[1] == "side":
+                    if side is None:             # RCCL enqueues on the CURRENT stream: the halo branch's collectives
+                        side = e.halo_stream()   # run on the side stream (entered once, left when the step ends)
+                        side.__enter__()
+                elif side is not None:
+                    side.__exit__(None, None, None)
+                    side = None
+                reply = getattr(x, req[0])(*req[2:])
+        except StopIteration as stop:
+            return stop.value
+        finally:
+            if side is not None:
+                side.__exit__(None, None, None)
+
     def step(self):
-        e, x, R, r = self.engine, self.x, self.world, self.rank
+        self._drive(self._step_gen())
+
+    def _step_gen(self):
+        e, R, r = self.engine, self.world, self.rank
         rows, gids, n = e.rows_in, e.gids_in, self.n_in
         self._dirty = True
         several = R > 1 or self.exercise
@@ -588,7 +673,7 @@ class DistributedCollider:
 
         if repartition:
             # 1. ONE all-gather: every rank's centre range and sample rows -> global scene range, splitters
-            gathered = x.all_gather(e.sample_and_range(rows, n))       # [R, SAMPLES + 2, 4]
+            gathered = yield ("all_gather", "main", e.sample_and_range(rows, n))      # [R, SAMPLES + 2, 4]
             # 2. spatial repartition: fixed-size slots, nothing here waits for the device
             pslot = self.part_slot
             e.ensure_partition_slots(pslot, R)
@@ -597,7 +682,7 @@ class DistributedCollider:
             split = self._splits.get(pslot)
             if split is None:
                 split = self._splits[pslot] = tuple(pslot + 1 if q != r else 0 for q in range(R))
-            x.all_to_all_v(e.part_send, split, e.part_recv, split)
+            yield ("all_to_all_v", "main", e.part_send, split, e.part_recv, split)
             e.partition_unpack(R, r, pslot)
             e.mark_fork()
             own_rows, own_gids = e.owned_rows, e.owned_gids
@@ -619,23 +704,26 @@ class DistributedCollider:
             slot = self.slot
             e.ensure_slots(slot, len(self.peers_out), len(self.peers_in))
             e.fork()
-            with e.halo_stream():
-                boxes = x.all_gather(e.region_boxes(own_rows, m, repartition))   # [R, 8 boxes, 8], stays on the device
-                e.select_and_pack(own_rows, own_gids, m, boxes, self.peers_out, slot)
-                rows_io = self._halo_splits.get(slot)
-                if rows_io is None:
-                    rows_io = self._halo_splits[slot] = (tuple(slot + 1 if q in self.peers_out else 0 for q in range(R)),
-                                                         tuple(slot + 1 if q in self.peers_in else 0 for q in range(R)))
-                x.all_to_all_v(e.halo_send, rows_io[0], e.halo_recv, rows_io[1])
+            boxes = yield ("all_gather", "side", e.region_boxes(own_rows, m, repartition))   # [R, 8 boxes, 8], on the device
+            e.select_and_pack(own_rows, own_gids, m, boxes, self.peers_out, slot)
+            rows_io = self._halo_splits.get(slot)
+            if rows_io is None:
+                rows_io = self._halo_splits[slot] = (tuple(slot + 1 if q in self.peers_out else 0 for q in range(R)),
+                                                     tuple(slot + 1 if q in self.peers_in else 0 for q in range(R)))
+            yield ("all_to_all_v", "side", e.halo_send, rows_io[0], e.halo_recv, rows_io[1])
             # 4. ghosts as queries against my tree (slot lengths are read from the headers on the device)
             e.join()
             e.ghost_queries(len(self.peers_in), slot, own_gids)
 
     # -- results -------------------------------------------------------------------------------
     def synchronize(self):
-        """Wait for the enqueued steps.  If a slot (repartition or halo) overflowed in the last step (seen in
-        its header), every rank raises that slot size and the step is repeated, so what is read afterwards is
-        exact; otherwise the slot sizes follow the longest lists any rank has seen."""
+        """Wait for the enqueued steps.  If a halo slot overflowed in the last step (seen in its header), every
+        rank raises the slot size and the step is repeated, so what is read afterwards is exact; otherwise the
+        slot sizes follow the longest lists any rank has seen (a repartition slot that overflowed lost nothing --
+        the surplus stayed with its sender -- and simply grows for the steps that follow)."""
+        self._drive(self._sync_gen())
+
+    def _sync_gen(self):
         e = self.engine
         e.synchronize()
         if not self._dirty or not (self.world > 1 or self.exercise):
@@ -644,24 +732,31 @@ class DistributedCollider:
         cap = roundUp(self.capacity, 1024)
         while True:
             longest, ghosts, longest_part = e.halo_stats()
-            longest, longest_part = self.x.all_reduce([longest, longest_part], "max")
+            longest, longest_part = yield ("all_reduce", "main", [longest, longest_part], "max")
+            # (both are all-reduced: every rank takes the same decisions below and leaves together)
+            if max(longest, longest_part) > cap:     # (cannot happen: a list is a subset of what one rank holds)
+                raise RuntimeError("a list of %d records cannot fit any slot (rank capacity %d)"
+                                   % (max(longest, longest_part), self.capacity))
             self.stats["ghosts"] = ghosts
             self.stats["halo_slot"], self.stats["partition_slot"] = self.slot, self.part_slot
             want = max(4096, roundUp(longest + longest // 2 + 1024, 1024))
-            want_p = max(1024, roundUp(longest_part + longest_part // 16 + 2048, 1024))      # padding travels: keep it small
-            again = False
+            floor_p = self.MIN_PARTITION_SLOT
+            want_p = max(floor_p, roundUp(longest_part + longest_part // 16 + 2 * floor_p, floor_p))   # padding travels: keep it small
             if longest_part > self.part_slot:
-                self.part_slot, again = min(want_p, cap), True
+                self.part_slot = min(want_p, cap)
+                self.stats["partition_overflows"] += 1
             elif 20 * want_p <= 17 * self.part_slot:        # (shrink with hysteresis: lists that breathe by a few % keep their slot)
                 self.part_slot = want_p
+            again = False
             if longest > self.slot:
                 self.slot, again = min(want, cap), True
             elif self.partition != "hash" and (want < self.slot // 2 or want > self.slot):
                 self.slot = min(want, cap)
+            self.stats["halo_slot_next"], self.stats["partition_slot_next"] = self.slot, self.part_slot
             if not again:
                 break
             self.repeats += 1
-            self.step()
+            yield from self._step_gen()
             e.synchronize()
         self._dirty = False
 
@@ -677,3 +772,122 @@ class DistributedCollider:
         """(count, 2) uint32 global ids found by this rank (local x local, then ghost x local)."""
         self.synchronize()
         return self.engine.read_pairs()
+
+
+# --------------------------------------------------------------------------- several ranks in one process
+class LoopbackPort:
+    """The 'exchange' of one rank of a LoopbackWorld: it only names the rank; the world moves the data."""
+    nccl = False
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def _refuse(self, *a, **k):
+        raise RuntimeError("a LoopbackWorld rank is driven by the world (world.step() / world.synchronize())")
+
+    all_gather = all_to_all_v = all_reduce = _refuse
+
+
+class LoopbackWorld:
+    """R ranks of the protocol in ONE process on ONE device, for rehearsing a multi-GPU configuration on a one-GPU
+    box (BASELINE config 4: world 8 x 2 M spheres).  Every rank is a full DistributedCollider with its own engine
+    (buffers, tree, streams); the world runs the ranks' protocol generators in lockstep -- all ranks up to their
+    next collective, then the collective as plain copies between the ranks' buffers -- so each rank executes exactly
+    the launches, slot layouts and host decisions it would execute under torch.distributed.  What it cannot show is
+    the wire: collective latency and xGMI bandwidth.  With ``timed=True`` every segment between two collectives is
+    run to completion rank by rank and its device time recorded (``segments[rank] = [(ends_with, ms), ...]``): the
+    per-rank critical path of a step minus the collectives."""
+
+    def __init__(self, ctx, world, n_locals, engine=None, **kw):
+        import torch
+        self.torch = torch
+        n_agreed = max(int(v) for v in n_locals)
+        self.ranks = [DistributedCollider(ctx, None, int(n_locals[r]), engine=engine, exchange=LoopbackPort(r, world),
+                                          n_agreed=n_agreed, **kw) for r in range(world)]
+        self.world = world
+        self.segments = [[] for _ in range(world)]
+        self._gpu = self.ranks[0].engine.device.type != "cpu"
+
+    def _device_sync(self):
+        if self._gpu:
+            self.torch.cuda.synchronize()
+
+    def _run(self, gens, timed=False):
+        R, torch = self.world, self.torch
+        replies = [None] * R
+        if timed:
+            self.segments = [[] for _ in range(R)]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        while True:
+            reqs = []
+            for r, g in enumerate(gens):
+                e = self.ranks[r].engine
+                if timed:
+                    self._device_sync()
+                    ev[0].record(e.main)
+                try:
+                    reqs.append(g.send(replies[r]))
+                except StopIteration:
+                    reqs.append(None)
+                if timed:
+                    ev[1].record(e.main)
+                    ev[2].record(e.side)
+                    self._device_sync()
+                    self.segments[r].append((reqs[-1][0] if reqs[-1] else "end",
+                                             max(ev[0].elapsed_time(ev[1]), ev[0].elapsed_time(ev[2]))))
+            done = [q is None for q in reqs]
+            if all(done):
+                return
+            if any(done) or len({q[0] for q in reqs}) != 1:
+                raise RuntimeError("the ranks left the protocol at different points: %r" % [q and q[0] for q in reqs])
+            self._device_sync()
+            replies = getattr(self, "_" + reqs[0][0])([q[2:] for q in reqs])
+            self._device_sync()
+
+    # the collectives, as copies between the ranks' buffers (same layouts as Exchange)
+    def _all_gather(self, args):
+        out = self.torch.stack([a[0] for a in args])
+        return [out] * self.world
+
+    def _all_to_all_v(self, args):
+        R = self.world
+        offs = [(np.concatenate([[0], np.cumsum(a[1])]).astype(int), np.concatenate([[0], np.cumsum(a[3])]).astype(int))
+                for a in args]
+        for r in range(R):
+            recv, rc, ro = args[r][2], args[r][3], offs[r][1]
+            for q in range(R):
+                send, sc, so = args[q][0], args[q][1], offs[q][0]
+                if sc[r] != rc[q]:
+                    raise RuntimeError("rank %d sends %d records to rank %d, which expects %d" % (q, sc[r], r, rc[q]))
+                if rc[q]:
+                    recv[ro[q]:ro[q + 1]] = send[so[r]:so[r + 1]]
+        return [None] * R
+
+    def _all_reduce(self, args):
+        vals = [a[0] if isinstance(a[0], (list, tuple)) else [a[0]] for a in args]
+        op = max if (len(args[0]) > 1 and args[0][1] == "max") else sum
+        out = [int(op(v[k] for v in vals)) for k in range(len(vals[0]))]
+        return [out if isinstance(args[r][0], (list, tuple)) else out[0] for r in range(self.world)]
+
+    # the world's view of the collider API
+    def set_local_spheres(self, rank, coords4, radii, gids):
+        self.ranks[rank].set_local_spheres(coords4, radii, gids)
+
+    def step(self, timed=False):
+        self._run([dc._step_gen() for dc in self.ranks], timed)
+
+    def synchronize(self):
+        self._run([dc._sync_gen() for dc in self.ranks])
+
+    def adopt_owned(self):
+        for dc in self.ranks:
+            dc.adopt_owned()
+
+    def pairs(self):
+        """Every rank's pairs (global ids), after a synchronize()."""
+        self.synchronize()
+        return [dc.engine.read_pairs() for dc in self.ranks]
+
+    def global_pair_count(self):
+        self.synchronize()
+        return sum(dc.engine.pair_count() for dc in self.ranks)

@@ -266,15 +266,19 @@ int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint3
                        int coord_bytes);
 /* col_partition_group (2 launches): stable grouping by owner (one radix scatter of (dest, iota) into
  * (owners_sorted, perm); iota = 0, 1, 2, ...), then packing: the rows this rank keeps go to the front of
- * own_rows / own_gids / own_radii; the others into `send`: one SLOT of 1 + slot transport records per other rank
- * (rank order) -- a header record whose first word is the full length of the list, then min(length, slot)
- * records.  flags[2] = max(flags[2], longest list). */
+ * own_rows / own_gids / own_radii (`capacity` rows each); the others into `send`: one SLOT of 1 + slot transport
+ * records per other rank (rank order) -- a header record whose first word is the full length of the list, then
+ * min(length, slot) records.  Rows of a list beyond its slot STAY with this rank: they follow the kept rows in the
+ * owned arrays (owner order), so a slot that is too small never loses a sphere (ownership only decides load
+ * balance and halo size).  flags[2] = max(flags[2], longest list). */
 int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
                         const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world,
                         uint32_t rank, uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows,
-                        uint32_t *own_gids, void *own_radii, uint32_t *flags, int coord_bytes);
+                        uint32_t *own_gids, void *own_radii, uint32_t capacity, uint32_t *flags, int coord_bytes);
 /* col_partition_unpack (1 launch): recv = the slots received from the other ranks (laid out as `send`) appended to
- * the owned arrays behind the owner_counts[rank] rows the rank kept.  owned[0] = min(m, capacity), owned[1] = m
+ * the owned arrays behind the rows col_partition_group left there (owner_counts[rank] kept rows + the overflow of
+ * the lists it sent: sum over q != rank of max(owner_counts[q] - slot, 0)); a received header longer than the slot
+ * means the sender kept the rest.  owned[0] = min(m, capacity), owned[1] = m
  * (device words), *host_word (host-visible 64-bit word, e.g. col_host_alloc; may be NULL) = seq << 32 | m: the
  * host waits for that word only, then sizes the local pipeline.  flags[2] = max(flags[2], longest header). */
 int col_partition_unpack(void *stream, const void *recv, uint32_t world, uint32_t rank, uint32_t slot,

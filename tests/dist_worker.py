@@ -210,6 +210,61 @@ def hip_read(cq, buf, dtype, shape):
     return hip.read_buffer(cq, buf, dtype, shape)
 
 
+def moving_scene(dc, dist, mode, coords, radii, gids, out, steps=12):
+    """Every sphere moves a few radii per step (tests/motion.py) where it lives: step, adopt_owned, advance, step ...
+    with the repartition slots adapted to what the first (motionless) adopted step needed, so the lists of the
+    moving scene outgrow them.  Every step: the union of all ranks' pairs == brute force on the advanced scene, and
+    the owned sets of all ranks are a partition of the scene (no sphere lost or duplicated)."""
+    import oracle
+    from tests import motion
+    rank, world = dist.get_rank(), dist.get_world_size()
+    type(dc).MIN_PARTITION_SLOT = 8                # (let the slots really shrink to the lists of a scene at rest)
+    unit = motion.unit_for(float(np.median(radii)))
+    ref = coords.copy()
+    dc.step()
+    dc.synchronize()
+    dc.adopt_owned()
+    dc.step()
+    dc.synchronize()                               # nothing moved: every list is empty, the slots shrink
+    problems, cnt = [], 0
+    for k in range(steps):
+        dc.adopt_owned()
+        motion.advance_torch(dc.local_rows(), dc.local_gids(), k, unit)
+        motion.advance_numpy(ref, gids, k, unit)
+        dc.step()
+        pairs = dc.local_pairs()
+        total = dc.global_pair_count()
+        owned = dc.own_gids[:dc.n_owned].cpu().numpy().view(np.uint32).copy()
+        rows = dc.own_rows[:dc.n_owned].cpu().numpy().copy()
+        gathered = [None] * world
+        dist.gather_object((pairs, owned, rows), gathered if rank == 0 else None, dst=0)
+        if rank == 0:
+            cnt, want = oracle.brute_force(ref, radii)
+            got = [tuple(sorted(t)) for p, _, _ in gathered for t in p.tolist()]
+            all_owned = np.concatenate([o for _, o, _ in gathered])
+            all_rows = np.concatenate([r for _, _, r in gathered])
+            order = np.argsort(all_owned, kind="stable")
+            if not (len(got) == len(set(got)) == cnt == total and set(got) == set(map(tuple, want.tolist()))):
+                problems.append("step %d: %d pairs (%d unique, counted %d), brute force %d" % (k, len(got), len(set(got)), total, cnt))
+            if not np.array_equal(all_owned[order], gids):
+                problems.append("step %d: the owned sets are not a partition of the scene (%d of %d)" % (k, len(all_owned), len(gids)))
+            elif not (np.array_equal(all_rows[order][:, :3], ref[:, :3]) and np.array_equal(all_rows[order][:, 3], radii)):
+                problems.append("step %d: owned rows differ from the advanced scene" % k)
+    stats = dict(dc.stats)
+    stats["repeats"] = dc.repeats
+    if mode == "gpu":
+        stats["rank_parity"] = per_rank_parity(dc)
+    gathered = [None] * world
+    dist.gather_object(stats, gathered if rank == 0 else None, dst=0)
+    if rank == 0:
+        result = {"ok": not problems, "problems": problems, "stats": gathered, "world": world, "steps": steps,
+                  "expected": cnt, "mode": mode}
+        Path(out).write_text(json.dumps(result))
+        print(json.dumps(result))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     mode, partition, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kind = sys.argv[5] if len(sys.argv) > 5 else "uniform"
@@ -217,6 +272,7 @@ def main():
     part_slot = int(sys.argv[8]) if len(sys.argv) > 8 and int(sys.argv[8]) > 0 else None
     check = sys.argv[9] if len(sys.argv) > 9 else "brute"      # "single": against the single-GPU path (large scenes)
     adopt = len(sys.argv) > 10 and sys.argv[10] == "adopt"     # feed the owned spheres back as the next step's input
+    move = len(sys.argv) > 10 and sys.argv[10] == "move"       # ... and advance every sphere between the steps
     coord_dtype = np.dtype(sys.argv[7]) if len(sys.argv) > 7 else np.dtype("float32")
     import torch  # noqa: F401
     import torch.distributed as dist
@@ -231,14 +287,14 @@ def main():
     mine = hash_owner(gids, world) == rank
     ctx = hip.Context(0)
     engine = None
-    if mode == "cpu":
-        from collision_amd.misc import roundUp
-        cap = roundUp(int(int(mine.sum()) * 3.0) + 4096, 2 * 64)     # as DistributedCollider sizes it (slack 3)
-        engine = OracleEngine(cap, 1 << 20, coord_dtype)
+    if mode == "cpu":            # (a factory: the rank capacity is agreed over all ranks inside DistributedCollider)
+        engine = lambda cap: OracleEngine(cap, 1 << 20, coord_dtype)
     dc = DistributedCollider(ctx, dist, int(mine.sum()), group_size=64, pair_capacity=1 << 22, partition=partition,
                              slack=3.0, engine=engine, halo_slot=halo_slot, coord_dtype=coord_dtype,
                              partition_slot=part_slot)
     dc.set_local_spheres(coords[mine], radii[mine], gids[mine])
+    if move:
+        return moving_scene(dc, dist, mode, coords, radii, gids, out)
     for _ in range(2):                       # twice: buffers are reused across steps
         dc.step()
     dc.synchronize()

@@ -71,13 +71,34 @@ def test_halo_slot_overflow_is_repaired(tmp_path):
     assert all(s["repeats"] >= 1 and s["halo_slot"] >= 4096 for s in res["stats"])
 
 
-def test_partition_slot_overflow_is_repaired(tmp_path):
+def test_partition_slot_overflow_loses_nothing(tmp_path):
     """The repartition travels in fixed-size slots too (one per other rank, the list length in the header, what a
-    rank keeps does not travel).  Slots that start too small truncate the lists; synchronize() sees the headers,
-    every rank grows the slot and the step is repeated."""
+    rank keeps does not travel).  What does not fit into a slot STAYS with the sending rank -- ownership decides
+    load balance and halo size, never the pair set -- so the result is exact WITHOUT a repeat; synchronize() sees
+    the headers and grows the slot for the steps that follow."""
     res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29643, part_slot=16)
     assert res["ok"], res
-    assert all(s["repeats"] >= 1 and s["partition_slot"] > 16 for s in res["stats"])
+    assert all(s["repeats"] == 0 and s["partition_overflows"] >= 1 and s["partition_slot_next"] > 16 for s in res["stats"])
+    assert sum(s["owned"] for s in res["stats"]) == 1500
+
+
+@pytest.mark.parametrize("partition", ["morton", "hash"])
+def test_unequal_rank_sizes_agree_on_buffer_sizes(tmp_path, partition):
+    """n_local differs from rank to rank (1281 spheres hash to 3 ranks: 440 / 432 / 409); the capacities and slot
+    sizes of the fixed-size exchanges must come out equal on every rank (one all-reduce in the constructor)."""
+    res = _run(3, "cpu", partition, 1281, tmp_path, "uniform", port=29671 + (partition == "hash"))
+    assert res["ok"], res
+    assert len({s["halo_slot"] for s in res["stats"]}) == 1 and len({s["partition_slot"] for s in res["stats"]}) == 1
+
+
+def test_moving_spheres_with_adopted_ownership(tmp_path):
+    """adopt_owned() + motion: every sphere moves a few radii per step for 12 steps, the repartition slots start
+    from what a scene at rest needs (nearly nothing), so the lists outgrow them.  Pair set exact at every step, the
+    owned sets stay a partition of the scene."""
+    res = _run(3, "cpu", "morton", 1500, tmp_path, "clustered", port=29673, adopt="move")
+    assert res["ok"], res["problems"]
+    assert res["steps"] >= 10 and res["expected"] > 100
+    assert any(s["partition_overflows"] >= 1 for s in res["stats"])      # the slots really were outgrown
 
 
 def test_adopting_the_owned_spheres_keeps_the_result(tmp_path):
@@ -153,10 +174,26 @@ def test_adopting_the_owned_spheres_keeps_the_result_on_the_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_partition_slot_overflow_is_repaired_on_the_gpu(tmp_path):
+def test_partition_slot_overflow_loses_nothing_on_the_gpu(tmp_path):
     res = _run(3, "gpu", "morton", 30000, tmp_path, "uniform", port=29647, part_slot=256)
     assert res["ok"], res
-    assert all(s["repeats"] >= 1 and s["rank_parity"] == "ok" for s in res["stats"])
+    assert all(s["partition_overflows"] >= 1 and s["rank_parity"] == "ok" for s in res["stats"])
+    assert sum(s["owned"] for s in res["stats"]) == 30000
+
+
+@pytest.mark.gpu
+def test_moving_spheres_with_adopted_ownership_on_the_gpu(tmp_path):
+    res = _run(4, "gpu", "morton", 12000, tmp_path, "clustered", port=29674, adopt="move")
+    assert res["ok"], res["problems"]
+    assert res["steps"] >= 10
+    assert any(s["partition_overflows"] >= 1 for s in res["stats"])
+    assert all(s["rank_parity"] == "ok" for s in res["stats"])
+
+
+@pytest.mark.gpu
+def test_unequal_rank_sizes_on_the_gpu(tmp_path):
+    res = _run(3, "gpu", "morton", 12811, tmp_path, "uniform", port=29675)
+    assert res["ok"], res
 
 
 @pytest.mark.gpu
@@ -197,3 +234,20 @@ print("ok")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0 and "ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed as a plain command (no launcher, WORLD_SIZE unset): the parent starts the ranks
+    as a child torch.distributed.run and rank 0's JSON line comes out with n_gpus 2 (gloo here: both ranks share
+    the one GPU of the test box; the driver's 8-GPU node runs the same command over RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(COLLISION_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                           "--no-radix", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["spheres_total"] == 4000000 and res["value"] > 0
+    assert res["pairs_found"] > 100000

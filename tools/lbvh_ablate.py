@@ -6,12 +6,13 @@ from collision_amd._lib import call, cdll
 from collision_amd.collision import Collider
 import bench
 ctx = hip.Context(); cq = hip.CommandQueue(ctx)
-n = 1000000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 coords, radii = bench.uniform_scene(n)
+radii[:] = bench.RADIUS * (1e6 / n) ** (1.0 / 3.0)
 cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
-nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, (1 << 17) * 8)
+nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, (1 << 20) * 8)
 col = Collider(ctx, n, 64, 256)
-col.get_collisions(cq, cb, rb, nb, pb, 1 << 17); cq.finish()
+col.get_collisions(cq, cb, rb, nb, pb, 1 << 20); cq.finish()
 scratch = hip.Buffer(ctx, call.col_lbvh_scratch_bytes(n, 4))
 def run():
     call.col_lbvh(cq.stream, col._codes_bufs[1].ptr, col._ids_bufs[1].ptr, cb.ptr, rb.ptr, col._nodes_buf.ptr,
