@@ -44,7 +44,7 @@ _PROTOS = {
     "col_reduce_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "col_reduce": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "col_reduce_list": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
-                               C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
+                               C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "col_morton": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "col_scan_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "col_scan_u32": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),

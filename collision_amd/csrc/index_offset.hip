@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void k_index(const V *__restrict__ in, const I
 template <typename V, bool GATHER>
 int by_index(hipStream_t s, const void *in, const void *idx, void *out, uint64_t n, int index_bytes) {
     dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
-    if (index_bytes == 4) k_index<V, uint32_t, GATHER><<<grid, block, 0, s>>>((const V *)in, (const uint32_t *)idx, (V *)out, n);
+    if (index_bytes == 1) k_index<V, uint8_t, GATHER><<<grid, block, 0, s>>>((const V *)in, (const uint8_t *)idx, (V *)out, n);
+    else if (index_bytes == 2) k_index<V, uint16_t, GATHER><<<grid, block, 0, s>>>((const V *)in, (const uint16_t *)idx, (V *)out, n);
+    else if (index_bytes == 4) k_index<V, uint32_t, GATHER><<<grid, block, 0, s>>>((const V *)in, (const uint32_t *)idx, (V *)out, n);
     else if (index_bytes == 8) k_index<V, uint64_t, GATHER><<<grid, block, 0, s>>>((const V *)in, (const uint64_t *)idx, (V *)out, n);
     else return COL_EINVAL;
     COL_LAUNCH_OK();
@@ -54,9 +56,9 @@ template <typename V, typename O>
 __global__ __launch_bounds__(256) void k_find_offsets(const V *__restrict__ values, O *__restrict__ offsets, uint64_t n_pairs) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= n_pairs) return;
-    const V a = values[g], b = values[g + 1];
-    for (V v = a + 1; v <= b && v != 0; v++) offsets[v] = (O)(g + 1);
-    if (g <= values[0]) offsets[g] = 0;
+    const uint64_t a = values[g], b = values[g + 1];      // (in 64 bits: no wrap at the value type's maximum)
+    for (uint64_t v = a + 1; v <= b && v != 0; v++) offsets[v] = (O)(g + 1);
+    if (g <= (uint64_t)values[0]) offsets[g] = 0;
 }
 
 }  // namespace
@@ -75,18 +77,32 @@ int col_find_offsets(void *stream, const void *values, uint64_t n_values, void *
     hipStream_t s = col_stream(stream);
     // offset.py:41-45: fill with n_values first
     int rc;
-    if (offset_bytes == 4) { uint32_t v = (uint32_t)n_values; rc = col_fill(stream, offsets, &v, 4, n_offsets); }
+    if (offset_bytes == 1) { uint8_t v = (uint8_t)n_values; rc = col_fill(stream, offsets, &v, 1, n_offsets); }
+    else if (offset_bytes == 2) { uint16_t v = (uint16_t)n_values; rc = col_fill(stream, offsets, &v, 2, n_offsets); }
+    else if (offset_bytes == 4) { uint32_t v = (uint32_t)n_values; rc = col_fill(stream, offsets, &v, 4, n_offsets); }
     else if (offset_bytes == 8) { uint64_t v = n_values; rc = col_fill(stream, offsets, &v, 8, n_offsets); }
     else return COL_EINVAL;
     if (rc) return rc;
+    if (value_bytes != 1 && value_bytes != 2 && value_bytes != 4 && value_bytes != 8) return COL_EINVAL;
     if (n_values < 2) return COL_OK;
     const uint64_t np = n_values - 1;
     dim3 grid((unsigned)col_ceil_div(np, 256)), block(256);
-    if (value_bytes == 4 && offset_bytes == 4) k_find_offsets<uint32_t, uint32_t><<<grid, block, 0, s>>>((const uint32_t *)values, (uint32_t *)offsets, np);
-    else if (value_bytes == 4 && offset_bytes == 8) k_find_offsets<uint32_t, uint64_t><<<grid, block, 0, s>>>((const uint32_t *)values, (uint64_t *)offsets, np);
-    else if (value_bytes == 8 && offset_bytes == 4) k_find_offsets<uint64_t, uint32_t><<<grid, block, 0, s>>>((const uint64_t *)values, (uint32_t *)offsets, np);
-    else if (value_bytes == 8 && offset_bytes == 8) k_find_offsets<uint64_t, uint64_t><<<grid, block, 0, s>>>((const uint64_t *)values, (uint64_t *)offsets, np);
-    else return COL_EINVAL;
+#define COL_OFFSETS(V, O) k_find_offsets<V, O><<<grid, block, 0, s>>>((const V *)values, (O *)offsets, np)
+#define COL_OFFSETS_BY_O(V)                                  \
+    switch (offset_bytes) {                                  \
+    case 1: COL_OFFSETS(V, uint8_t); break;                  \
+    case 2: COL_OFFSETS(V, uint16_t); break;                 \
+    case 4: COL_OFFSETS(V, uint32_t); break;                 \
+    default: COL_OFFSETS(V, uint64_t); break;                \
+    }
+    switch (value_bytes) {
+    case 1: COL_OFFSETS_BY_O(uint8_t); break;
+    case 2: COL_OFFSETS_BY_O(uint16_t); break;
+    case 4: COL_OFFSETS_BY_O(uint32_t); break;
+    default: COL_OFFSETS_BY_O(uint64_t); break;
+    }
+#undef COL_OFFSETS_BY_O
+#undef COL_OFFSETS
     COL_LAUNCH_OK();
     return COL_OK;
 }

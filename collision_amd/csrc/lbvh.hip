@@ -11,11 +11,13 @@
 // over the leaf boxes, and min/max are exact and idempotent: any grouping gives the reference's
 // bits.  So there is no inter-workgroup hand-off at all:
 //
-//   k_chunk   one block per 256 consecutive sorted leaves: leaf boxes -> LDS sparse table
-//             (9 levels x 256 x 6 scalars), Karras topology for internal nodes [c*256, c*256+256),
-//             box of every node whose range stays inside the chunk = 2 table look-ups, written
-//             as one 32-byte record (box + traversal links) per thread.  A node that crosses the
-//             chunk boundary stores the half of its range that lies in this chunk (`partial`).
+//   k_chunk   one block per 256 consecutive sorted leaves: sorted codes staged in an LDS window
+//             (chunk +- 256) for Karras' dependent probes; leaf boxes -> LDS; Karras topology for
+//             internal nodes [c*256, c*256+256); a node whose range stays inside the chunk waits in
+//             LDS (workgroup scope) until both children are final, merges them and publishes its
+//             box; every node is written as one 32-byte record (box + traversal links) per thread.
+//             A node that crosses the chunk boundary stores the half of its range that lies in this
+//             chunk (`partial`: the prefix / suffix unions of the chunk's leaf boxes).
 //   k_group   (1-2 tiny launches) sparse tables over chunk totals, 256 chunks per group,
 //             then over group totals, ...
 //   k_cross   the ~1-2 % of nodes that cross chunks: partial[first] U partial[last] U

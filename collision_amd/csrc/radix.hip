@@ -851,6 +851,19 @@ __global__ __launch_bounds__(256) void k_iota(u32 *__restrict__ out, uint64_t n)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (u32)i;
 }
+// uint8 / uint16 keys (radix.py:16-20 accepts every unsigned dtype): widened to u32 for the sort -- one 8-bit pass
+// per key byte -- and narrowed again on the way out
+template <typename N>
+__global__ __launch_bounds__(256) void k_widen(const N *__restrict__ in, u32 *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (u32)in[i];
+}
+template <typename N>
+__global__ __launch_bounds__(256) void k_narrow(const u32 *__restrict__ in, N *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (N)in[i];
+}
+inline bool narrow_key(int key_bytes) { return key_bytes == 1 || key_bytes == 2; }
 // out[i] = in[idx[i]] for elements of CH chunks of type X (CH * sizeof(X) bytes): one chunk per thread
 template <typename X, int CH>
 __global__ __launch_bounds__(256) void k_gather_chunks(const X *__restrict__ in, const u32 *__restrict__ idx, X *__restrict__ out, uint64_t n) {
@@ -894,12 +907,15 @@ int col_debug_radix_stamps(uint64_t *out, int reset) {
 }
 
 uint32_t col_radix_tile(uint64_t n, int key_bytes, int val_bytes) {
+    if (narrow_key(key_bytes)) key_bytes = 4;
     return tile_for(n, key_bytes, wide_value(val_bytes) ? 4 : val_bytes);       // (wide values are sorted as (key, index) pairs)
 }
 
 // Monotone in n: sized for the largest histogram any n' <= n can need (see max_tiles_upto), so a scratch
 // buffer sized for n serves every smaller sort / col_collide call as well.
 size_t col_radix_scratch_bytes(uint64_t n, int key_bytes, int val_bytes) {
+    if (narrow_key(key_bytes))       // the u32 sort + the widened keys and their sorted image
+        return col_radix_scratch_bytes(n, 4, val_bytes) + 2 * align256((size_t)n * 4);
     if (wide_value(val_bytes))       // (key, index) sort + the index ramp and its sorted image
         return col_radix_scratch_bytes(n, key_bytes, 4) + 2 * align256((size_t)n * 4);
     const size_t nb = max_tiles_upto(n, key_bytes);
@@ -964,9 +980,49 @@ int col_radix_sort(void *stream, const void *keys, void *keys_out, const void *v
     return col_radix_sort_ex(stream, keys, keys_out, vals, vals_out, n, key_bytes, val_bytes, scratch, copy_back, 0);
 }
 
+static int sort_passes(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                       uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0, int passes);
+
 int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                       uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0) {
     if (!vals || !vals_out) val_bytes = 0;
+    if (narrow_key(key_bytes)) {
+        // uint8 / uint16 keys: widen, sort the low key_bytes digits as u32 keys (values ride along as usual), narrow
+        if (n >= 0xFFFFFFFFull || have_hist0 || !(native_value(val_bytes) || wide_value(val_bytes))) return COL_EINVAL;
+        if (n == 0) return COL_OK;
+        if (!scratch) return COL_ENOSCRATCH;
+        hipStream_t s = col_stream(stream);
+        char *q = (char *)scratch + col_radix_scratch_bytes(n, 4, val_bytes);
+        u32 *wide_in = (u32 *)q, *wide_out = (u32 *)(q + align256((size_t)n * 4));
+        dim3 grid((unsigned)col_ceil_div(n, 256)), block(256);
+        if (key_bytes == 1) k_widen<uint8_t><<<grid, block, 0, s>>>((const uint8_t *)keys, wide_in, n);
+        else k_widen<uint16_t><<<grid, block, 0, s>>>((const uint16_t *)keys, wide_in, n);
+        COL_LAUNCH_OK();
+        int rc;
+        if (wide_value(val_bytes)) {
+            char *q2 = (char *)scratch + col_radix_scratch_bytes(n, 4, 4);
+            u32 *iota = (u32 *)q2, *sorted_idx = (u32 *)(q2 + align256((size_t)n * 4));
+            k_iota<<<grid, block, 0, s>>>(iota, n);
+            COL_LAUNCH_OK();
+            if ((rc = sort_passes(stream, wide_in, wide_out, iota, sorted_idx, n, 4, 4, scratch, 0, 0, key_bytes))) return rc;
+            if ((rc = gather_values(s, vals, sorted_idx, vals_out, n, val_bytes))) return rc;
+        } else if ((rc = sort_passes(stream, wide_in, wide_out, vals, vals_out, n, 4, val_bytes, scratch, 0, 0, key_bytes))) return rc;
+        if (key_bytes == 1) k_narrow<uint8_t><<<grid, block, 0, s>>>(wide_out, (uint8_t *)keys_out, n);
+        else k_narrow<uint16_t><<<grid, block, 0, s>>>(wide_out, (uint16_t *)keys_out, n);
+        COL_LAUNCH_OK();
+        if (copy_back) {
+            COL_HIP(hipMemcpyAsync((void *)keys, keys_out, (size_t)n * key_bytes, hipMemcpyDeviceToDevice, s));
+            if (val_bytes) COL_HIP(hipMemcpyAsync((void *)vals, vals_out, (size_t)n * val_bytes, hipMemcpyDeviceToDevice, s));
+        }
+        return COL_OK;
+    }
+    return sort_passes(stream, keys, keys_out, vals, vals_out, n, key_bytes, val_bytes, scratch, copy_back, have_hist0, key_bytes);
+}
+
+// `passes` 8-bit digit passes from the least significant byte (= key_bytes for a full sort; fewer when the upper
+// key bytes are known to be zero); the last pass lands in *_out.
+static int sort_passes(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                       uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0, int passes) {
     if (wide_value(val_bytes)) {
         // values of a width the scatter kernel does not move: sort (key, index), gather the values once
         if (n >= 0xFFFFFFFFull || (key_bytes != 4 && key_bytes != 8)) return COL_EINVAL;
@@ -977,7 +1033,7 @@ int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void
         u32 *iota = (u32 *)q, *sorted_idx = (u32 *)(q + align256((size_t)n * 4));
         k_iota<<<dim3((unsigned)col_ceil_div(n, 256)), dim3(256), 0, s>>>(iota, n);
         COL_LAUNCH_OK();
-        int rc = col_radix_sort_ex(stream, keys, keys_out, iota, sorted_idx, n, key_bytes, 4, scratch, 0, 0);
+        int rc = sort_passes(stream, keys, keys_out, iota, sorted_idx, n, key_bytes, 4, scratch, 0, 0, passes);
         if (rc) return rc;
         if ((rc = gather_values(s, vals, sorted_idx, vals_out, n, val_bytes))) return rc;
         if (copy_back) {
@@ -996,11 +1052,10 @@ int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void
     void *scan_scratch = p;            p += align256(col_scan_scratch_bytes((uint64_t)RDIG * nb));
     void *tmp_keys = p;                p += align256((size_t)n * key_bytes);
     void *tmp_vals = p;                // (carved for THIS n: never more than col_radix_scratch_bytes(n) in total)
-    const int passes = key_bytes;      // 8-bit digits: 4 or 8 passes (even), so the last one lands in *_out
-    const void *src_k = keys, *src_v = vals;
+    const void *src_k = keys, *src_v = vals;       // 8-bit digits; the destinations alternate so that the last pass lands in *_out
     for (int pass = 0; pass < passes; pass++) {
-        void *dst_k = (pass & 1) ? keys_out : tmp_keys;
-        void *dst_v = (pass & 1) ? vals_out : tmp_vals;
+        void *dst_k = ((passes - 1 - pass) & 1) ? tmp_keys : keys_out;
+        void *dst_v = ((passes - 1 - pass) & 1) ? tmp_vals : vals_out;
         int rc = (pass == 0 && have_hist0) ? COL_OK : col_radix_histogram(stream, src_k, n, key_bytes, val_bytes, pass, hist);
         if (rc) return rc;
         rc = col_scan_u32(stream, hist, (uint64_t)RDIG * nb, scan_scratch);

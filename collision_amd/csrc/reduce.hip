@@ -171,11 +171,16 @@ int by_op(void *stream, const void *values, uint64_t n, int width, int op, void 
 // ADD macro, and MUL as its obvious sibling) and an initial value.  Output: one row of `width` scalars per
 // accumulator, in list order (ACC_SIZE consecutive VALDTYPEs, reduce.cl:34-37).  HBM-bound like the two
 // compiled-in lists; the op dispatch is a wave-uniform switch.
-struct AccList { int n; int op[COL_REDUCE_MAX_ACC]; double init[COL_REDUCE_MAX_ACC]; };
+struct AccList { int n; int op[COL_REDUCE_MAX_ACC]; double init[COL_REDUCE_MAX_ACC]; long long iinit[COL_REDUCE_MAX_ACC]; int exact[COL_REDUCE_MAX_ACC]; };
 
-template <typename T> __device__ __forceinline__ T init_value(double v) {
+// `exact`: the initial value of an integer list arrived as a 64-bit integer (a double cannot carry values beyond
+// 2^53, e.g. UINT64_MAX as the start of a min list); u64 values travel as their two's-complement bit pattern
+template <typename T> __device__ __forceinline__ T init_value(const AccList &L, int k) {
+    if (k >= L.n) return (T)0;
+    const double v = L.init[k];
     if (v == (double)INFINITY) return pos_inf<T>();
     if (v == -(double)INFINITY) return neg_inf<T>();
+    if constexpr (!__is_floating_point(T)) { if (L.exact[k]) return (T)(unsigned long long)L.iinit[k]; }
     return (T)v;
 }
 template <typename T> __device__ __forceinline__ T apply_op(int op, T a, T b) {
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(RT) void k_reduce_list1(const Row<T, W> *__restrict
     T a[COL_REDUCE_MAX_ACC][W];
     for (int k = 0; k < COL_REDUCE_MAX_ACC; k++)
 #pragma unroll
-        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(k < L.n ? L.init[k] : 0.0);
+        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(L, k);
     const uint64_t stride = (uint64_t)gridDim.x * RT;
     for (uint64_t i = (uint64_t)blockIdx.x * RT + threadIdx.x; i < n; i += stride) {
         const Row<T, W> r = rows[i];
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(RT) void k_reduce_list2(const T *partials, uint32_t
     T a[COL_REDUCE_MAX_ACC][W];
     for (int k = 0; k < COL_REDUCE_MAX_ACC; k++)
 #pragma unroll
-        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(k < L.n ? L.init[k] : 0.0);
+        for (int i = 0; i < W; i++) a[k][i] = init_value<T>(L, k);
     for (uint32_t p = threadIdx.x; p < nparts; p += RT)
         for (int k = 0; k < L.n; k++)
 #pragma unroll
@@ -314,7 +319,7 @@ size_t col_reduce_scratch_bytes(int dtype, int width) {
 }
 
 int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int width, int n_acc, const int *ops,
-                    const double *inits, void *scratch, void *out) {
+                    const double *inits, const int64_t *int_inits, void *scratch, void *out) {
     if (!scratch) return COL_ENOSCRATCH;
     if (n_acc < 1 || n_acc > COL_REDUCE_MAX_ACC || !ops || !inits) return COL_EINVAL;
     AccList L;
@@ -322,6 +327,8 @@ int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int
     for (int k = 0; k < COL_REDUCE_MAX_ACC; k++) {
         L.op[k] = k < n_acc ? ops[k] : COL_ACC_ADD;
         L.init[k] = k < n_acc ? inits[k] : 0.0;
+        L.exact[k] = k < n_acc && int_inits != nullptr;
+        L.iinit[k] = L.exact[k] ? (long long)int_inits[k] : 0;
         if (L.op[k] < COL_ACC_MIN || L.op[k] > COL_ACC_MUL) return COL_EINVAL;
     }
     switch (dtype) {

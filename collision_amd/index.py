@@ -15,8 +15,6 @@ class IndexProgram(ProgramHandle):
         self.index_dtype = np.dtype(index_dtype)
         if self.index_dtype not in _UNSIGNED:
             raise ValueError("Invalid index dtype: {}".format(self.index_dtype))
-        if self.index_dtype.itemsize not in (4, 8):
-            raise ValueError("Unsupported index dtype on this device path: {}".format(self.index_dtype))
         if dtype_sizeof(self.value_dtype) not in (1, 2, 4, 8, 16, 32):
             raise ValueError("Unsupported value dtype on this device path: {}".format(self.value_dtype))
         super().__init__(ctx)

@@ -16,8 +16,6 @@ class OffsetProgram(ProgramHandle):
         for what, dt in (("value", self.value_dtype), ("offset", self.offset_dtype)):
             if dt not in _UNSIGNED:
                 raise ValueError("Invalid {} dtype: {}".format(what, dt))
-            if dt.itemsize not in (4, 8):
-                raise ValueError("Unsupported {} dtype on this device path: {}".format(what, dt))
         super().__init__(ctx)
 
 

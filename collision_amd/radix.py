@@ -19,7 +19,7 @@ from .misc import ProgramHandle, device_width, nextPowerOf2, np_unsigned_dtypes,
 from .scan import PrefixScanProgram, PrefixScanner  # noqa: F401  (re-exported)
 
 _UNSIGNED = {np.dtype(name) for name in np_unsigned_dtypes}
-_KEY_BYTES = (4, 8)
+_KEY_BYTES = (1, 2, 4, 8)             # uint8 / uint16 keys are widened to u32 on the device, one pass per key byte
 _VALUE_BYTES = (1, 2, 4, 8, 16, 32, 64, 128)     # 1 / 2 / 64 / 128: sorted as (key, index), gathered once
 
 

@@ -28,13 +28,30 @@ _ACC_FN = {"min": 0, "fmin": 0, "max": 1, "fmax": 1, "ADD": 2, "MUL": 3}
 MAX_ACCUMULATORS = 4
 
 
-def _parse_init(text):
+def _parse_init(text, dtype):
+    """(value as a double, value as an exact 64-bit integer or None).  The reference renders the text verbatim into
+    the kernel; here it must be a number or [-]INFINITY.  Integer dtypes take integer initial values exactly
+    (a double is inexact beyond 2^53: UINT64_MAX as the start of a min list), and an unsigned dtype refuses a
+    negative one."""
     text = str(text).strip().replace("(", "").replace(")", "")
     if text in ("INFINITY", "+INFINITY"):
-        return float("inf")
+        return float("inf"), 0
     if text == "-INFINITY":
-        return float("-inf")
-    return float(text)            # ValueError for anything that is not a number
+        return float("-inf"), 0
+    value = float(text)           # ValueError for anything that is not a number
+    base = np.dtype(dtype).base
+    if base.kind not in "ui":
+        return value, None
+    try:
+        exact = int(text, 0)
+    except ValueError:
+        if value != int(value):
+            raise ValueError("Initial value {} is not an integer ({} accumulator)".format(text, base))
+        exact = int(value)
+    info = np.iinfo(base)
+    if not info.min <= exact <= info.max:
+        raise ValueError("Initial value {} outside the range of {}".format(text, base))
+    return value, exact - (1 << 64) if exact >= (1 << 63) else exact
 
 
 class ReductionProgram(ProgramHandle):
@@ -50,7 +67,11 @@ class ReductionProgram(ProgramHandle):
             if len(key) > MAX_ACCUMULATORS or any(fn not in _ACC_FN for _, fn in key):
                 raise ValueError("Unsupported accumulator list: {}".format(self.accumulator))
             self.acc_ops = (C.c_int * len(key))(*[_ACC_FN[fn] for _, fn in key])
-            self.acc_inits = (C.c_double * len(key))(*[_parse_init(init) for init, _ in key])
+            parsed = [_parse_init(init, self.value_dtype) for init, _ in key]
+            self.acc_inits = (C.c_double * len(key))(*[v for v, _ in parsed])
+            self.acc_int_inits = None              # exact integer initial values for the integer dtypes
+            if all(e is not None for _, e in parsed):
+                self.acc_int_inits = (C.c_int64 * len(key))(*[e for _, e in parsed])
         self.acc_dtype = np.dtype((self.value_dtype, len(key)))
         self.type_code = type_code(self.value_dtype)
         self.width = device_width(self.value_dtype)
@@ -91,7 +112,7 @@ class Reducer:
                             self._scratch.ptr, output_buf.ptr)
         else:
             call.col_reduce_list(cq.stream, values_buf.ptr, size, p.type_code, p.width, len(p.acc_ops), p.acc_ops,
-                                 p.acc_inits, self._scratch.ptr, output_buf.ptr)
+                                 p.acc_inits, p.acc_int_inits, self._scratch.ptr, output_buf.ptr)
         return hip.Event(cq)
 
 

@@ -29,6 +29,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libcollision_hip.so is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define COL_OK 0
 #define COL_EINVAL (-1)      /* bad argument (size/dtype combination not supported) */
@@ -94,14 +98,16 @@ int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int widt
                void *scratch, void *out);
 /* Any accumulator list (collision/reduce.py:9-22 renders a list of (init, fn) pairs into reduce.cl): n_acc <=
  * COL_REDUCE_MAX_ACC accumulators, ops[k] one of COL_ACC_*, inits[k] the initial value (+-INFINITY = the
- * type's extreme).  out: n_acc rows of `width` scalars, in list order (reduce.cl:34-37). */
+ * type's extreme).  int_inits (may be NULL): the same initial values as 64-bit integers, used for the integer
+ * dtypes where a double is inexact beyond 2^53 (u64 values as their two's-complement bit pattern; an entry whose
+ * inits[k] is +-INFINITY is ignored).  out: n_acc rows of `width` scalars, in list order (reduce.cl:34-37). */
 #define COL_REDUCE_MAX_ACC 4
 #define COL_ACC_MIN 0
 #define COL_ACC_MAX 1
 #define COL_ACC_ADD 2
 #define COL_ACC_MUL 3
 int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int width, int n_acc, const int *ops,
-                    const double *inits, void *scratch, void *out);
+                    const double *inits, const int64_t *int_inits, void *scratch, void *out);
 
 /* ---------------------------------------------------------------- morton
  * Replaces the `range` kernel, the padding fill and `calculateCodes`
@@ -326,6 +332,9 @@ int col_scatter(void *stream, const void *in, const void *indices, void *out, ui
 int col_find_offsets(void *stream, const void *values, uint64_t n_values, void *offsets,
                      uint64_t n_offsets, int value_bytes, int offset_bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,33 @@ def test_generic_accumulator_errors(hip_env):
     for cls in (Bad, TooMany):
         with pytest.raises(ValueError):
             cls(ctx, np.dtype("float32"))
+
+
+def test_integer_initial_values_are_exact(hip_env):
+    """Initial values of integer lists beyond 2^53 (a double cannot carry them): UINT64_MAX as the start of a min
+    list, 2^63 + 1 as the start of a max list over smaller data; a negative start for an unsigned dtype is refused."""
+    from collision_amd.reduce import ReductionProgram, Reducer
+    ctx, cq = hip_env
+    big = (1 << 63) + 1
+
+    class LimitsProgram(ReductionProgram):
+        accumulator = [(str((1 << 64) - 1), "min"), (str(big), "max"), ("0x7", "ADD")]
+
+    class Limits(Reducer):
+        program_type = LimitsProgram
+
+    values = np.array([(1 << 64) - 5, (1 << 63) - 1, 12345], dtype=np.uint64)
+    out_buf = hip.Buffer(ctx, 3 * 8)
+    e = Limits(ctx, 8, 64, np.dtype("uint64")).reduce(cq, len(values), upload(ctx, values), out_buf)
+    out = download(cq, out_buf, np.uint64, 3, wait_for=[e])
+    assert int(out[0]) == 12345 and int(out[1]) == (1 << 64) - 5 and int(out[2]) == (7 + int(values.sum(dtype=np.uint64))) % (1 << 64)
+    e = Limits(ctx, 8, 64, np.dtype("uint64")).reduce(cq, 2, upload(ctx, values[1:]), out_buf)      # max stays at its start
+    out = download(cq, out_buf, np.uint64, 3, wait_for=[e])
+    assert int(out[1]) == big
+
+    class Negative(ReductionProgram):
+        accumulator = [("-1", "max")]
+
+    with pytest.raises(ValueError):
+        Negative(ctx, np.dtype("uint32"))
+    Negative(ctx, np.dtype("int32"))          # fine for a signed dtype

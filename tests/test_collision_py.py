@@ -134,3 +134,19 @@ def test_get_collisions_survives_graph_capture_and_replay(hip_env, oracle):
             count = int(n_t.item())
             assert count == ref["count"]
             assert pair_set(p_t[:count].cpu().numpy().view(np.uint32)) == expected
+
+
+@pytest.mark.parametrize("size,r", [(2000, 0.005), (10000, 0.001)])
+def test_config1_scene_matches_the_reference_output(hip_env, generated, size, r):
+    """BASELINE config 1's scene (RandomState(4), r = 0.001, 10 000 spheres) through the HIP Collider against the pair
+    set the REFERENCE's own find_collisions produced on it (tests/golden/make_golden.py -> generated.npz): the one
+    fixture the reference itself computed at a BASELINE size."""
+    ctx, cq = hip_env
+    rng = np.random.RandomState(4)
+    coords = rng.random_sample((size, 3)).astype(np.float32)
+    radii = np.full(size, r, np.float32)
+    expected = pair_set(generated["config1_%d_pairs" % size])
+    collider = Collider(ctx, size, 16, 64)
+    count, pairs = run_collider(ctx, cq, collider, coords, radii, max(len(expected), 16))
+    assert count == len(expected)
+    assert pair_set(np.sort(pairs, axis=1)) == expected

@@ -11,7 +11,7 @@ from tests.util import download, upload
 pytestmark = pytest.mark.gpu
 
 VALUE_DTYPES = [np.dtype("uint32"), np.dtype(("float64", 2)), np.dtype(("float32", 4))]
-INDEX_DTYPES = [np.dtype("uint32"), np.dtype("uint64")]
+INDEX_DTYPES = [np.dtype("uint32"), np.dtype("uint64"), np.dtype("uint8"), np.dtype("uint16")]     # index.py:13-17: any unsigned dtype
 
 
 @pytest.mark.parametrize("value_dtype", VALUE_DTYPES, ids=str)
@@ -58,8 +58,8 @@ def test_index_program_errs(hip_env):
         Indexer(ctx, "uint32", "uint32", program=IndexProgram(ctx, "uint32", "uint64"))
 
 
-@pytest.mark.parametrize("value_dtype", ["uint32", "uint64"])
-@pytest.mark.parametrize("offset_dtype", ["uint32", "uint64"])
+@pytest.mark.parametrize("value_dtype", ["uint32", "uint64", "uint8", "uint16"])          # offset.py:14-19: any unsigned dtype
+@pytest.mark.parametrize("offset_dtype", ["uint32", "uint64", "uint8", "uint16"])
 def test_offset_goldens(hip_env, generated_meta, value_dtype, offset_dtype):
     ctx, cq = hip_env
     lits = generated_meta["offset_literals"]        # tests/test_offset_py.py:27-28,48-49
@@ -85,3 +85,19 @@ def test_offsets_match_oracle_and_searchsorted(hip_env, oracle):
         out = download(cq, out_buf, np.uint32, n_offsets, wait_for=[e])
         np.testing.assert_array_equal(out, oracle.find_offsets(values, n_offsets))
         np.testing.assert_array_equal(out, np.searchsorted(values, np.arange(n_offsets), side="left"))
+
+
+@pytest.mark.parametrize("value_dtype", ["uint8", "uint16"])
+def test_narrow_offsets_reach_the_type_maximum(hip_env, value_dtype):
+    """Values up to the type's maximum (the reference's own comment warns of the wrap at a == b == VALUE_TYPE_MAX:
+    the loop counter is 64 bits wide here)."""
+    ctx, cq = hip_env
+    top = int(np.iinfo(value_dtype).max)
+    rs = np.random.RandomState(4)
+    values = np.sort(rs.randint(0, top + 1, size=5000)).astype(value_dtype)
+    values[-3:] = top
+    n_offsets = top + 1
+    out_buf = hip.Buffer(ctx, n_offsets * 4)
+    e = OffsetFinder(ctx, value_dtype, "uint32").find_offsets(cq, upload(ctx, values), len(values), out_buf, n_offsets)
+    out = download(cq, out_buf, np.uint32, n_offsets, wait_for=[e])
+    np.testing.assert_array_equal(out, np.searchsorted(values, np.arange(n_offsets), side="left"))

@@ -101,8 +101,8 @@ def test_partition_plan(hip_env, oracle, dt, world, clustered):
 @pytest.mark.parametrize("world,rank,slot", [(1, 0, 64), (4, 2, 4096), (4, 0, 100), (8, 7, 2048)])
 def test_partition_group_and_unpack(hip_env, oracle, dt, world, rank, slot):
     """Grouping is stable; what the rank keeps lands at the front of its owned arrays; every other rank's list goes
-    into its slot (header = full length, then min(length, slot) records); the unpack appends received slots in rank
-    order and publishes the owned count."""
+    into its slot (header = full length, then min(length, slot) records) and what does not fit stays here, behind
+    the kept rows in owner order; the unpack appends received slots in rank order and publishes the owned count."""
     ctx, cq = hip_env
     cb = np.dtype(dt).itemsize
     rw = cb + 1                                                  # words per record: 4 scalars + gid
@@ -124,11 +124,15 @@ def test_partition_group_and_unpack(hip_env, oracle, dt, world, rank, slot):
              owned=upload(ctx, np.zeros(2, np.uint32)))
     call.col_partition_group(cq.stream, b["rows"].ptr, b["gids"].ptr, n, bufs["dest"].ptr, b["iota"].ptr, bufs["hist"].ptr,
                              bufs["counts"].ptr, world, rank, slot, b["owners"].ptr, b["perm"].ptr, b["send"].ptr,
-                             b["own_rows"].ptr, b["own_gids"].ptr, b["own_radii"].ptr, b["flags"].ptr, cb)
+                             b["own_rows"].ptr, b["own_gids"].ptr, b["own_radii"].ptr, cap, b["flags"].ptr, cb)
     perm = np.argsort(dest, kind="stable")
     np.testing.assert_array_equal(download(cq, b["perm"], np.uint32, n), perm)
     np.testing.assert_array_equal(download(cq, b["owners"], np.uint32, n), dest[perm])
     kept = perm[dest[perm] == rank]
+    stay = np.concatenate([kept] + [perm[dest[perm] == q][slot:] for q in range(world) if q != rank])
+    if slot == 100:
+        assert len(stay) > len(kept)                              # (this case really overflows its slots)
+    kept = stay
     np.testing.assert_array_equal(download(cq, b["own_rows"], dt, (cap, 4))[:len(kept)], rows[kept])
     np.testing.assert_array_equal(download(cq, b["own_gids"], np.uint32, cap)[:len(kept)], gids[kept])
     np.testing.assert_array_equal(download(cq, b["own_radii"], dt, cap)[:len(kept)], rows[kept, 3])

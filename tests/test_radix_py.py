@@ -212,6 +212,31 @@ def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
         np.testing.assert_array_equal(download(cq, vo, np.uint8, vals.shape), vals[order])
 
 
+@pytest.mark.parametrize("key_dtype", ["uint8", "uint16"])
+@pytest.mark.parametrize("value_dtype", [None, np.dtype("uint32"), np.dtype(("float32", 4)), np.dtype("uint8"), np.dtype(("float64", 8))])
+@pytest.mark.parametrize("n", [512, 200 * 1024])
+def test_narrow_keys(hip_env, key_dtype, value_dtype, n):
+    """uint8 / uint16 keys (radix.py:16-20 accepts every unsigned dtype): widened to u32 on the device, one 8-bit pass
+    per key byte, narrowed on the way out; values of every width follow stably."""
+    ctx, cq = hip_env
+    rs = np.random.RandomState(4)
+    keys = rs.randint(0, 2 ** (8 * np.dtype(key_dtype).itemsize), size=n).astype(key_dtype)
+    sorter = RadixSorter(ctx, n, 64, 4, key_dtype=key_dtype, value_dtype=value_dtype or np.dtype("uint32"))
+    assert sorter.num_passes == 2 * np.dtype(key_dtype).itemsize
+    kb, ko = upload(ctx, keys), hip.Buffer(ctx, keys.nbytes)
+    order = np.argsort(keys, kind="stable")
+    if value_dtype is None:
+        e = sorter.sort(cq, kb, ko)
+        np.testing.assert_array_equal(download(cq, ko, key_dtype, n, wait_for=[e]), keys[order])
+        return
+    vals = rs.randint(0, 255, size=(n, value_dtype.itemsize), dtype=np.uint8)
+    vb, vo = upload(ctx, vals), hip.Buffer(ctx, vals.nbytes)
+    e = sorter.sort(cq, kb, ko, vb, vo)
+    np.testing.assert_array_equal(download(cq, ko, key_dtype, n, wait_for=[e]), keys[order])
+    np.testing.assert_array_equal(download(cq, vo, np.uint8, vals.shape), vals[order])
+    np.testing.assert_array_equal(download(cq, kb, key_dtype, n), keys)          # inputs untouched
+
+
 def test_huge_tile_kernel(hip_env):
     """The 16384-key tile (u32 keys WITHOUT values; automatic from 32 Mi keys) has a kernel of its own
     (k_scatter_huge) and a separate instance for the input's partial last tile: forced here on small inputs --
