@@ -361,7 +361,11 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
 #define COL_DPP_STEP(ctrl)                                                      \
                 "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t" \
                 "v_max_f32_dpp %3, %3, %3 " ctrl "\n\tv_max_f32_dpp %4, %4, %4 " ctrl "\n\tv_max_f32_dpp %5, %5, %5 " ctrl "\n\t"
-                asm volatile(COL_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                // (s_nop 1 first: a DPP read needs two wait states after the VALU write of its source, and the
+                // compiler does not track that hazard across the asm boundary -- the inputs are copies it makes
+                // right before the block)
+                asm volatile("s_nop 1\n\t"
+                             COL_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
                              COL_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
                              COL_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
                              COL_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
@@ -448,11 +452,14 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
+            // (the asm walk narrows EXEC with v_cmpx and restores the mask it found on entry -- the full wave here:
+            // 1024-thread blocks, wave-uniform control flow above)
             while (idx != END) {
-                u64 hits;
+                u64 hits, exec0;
                 u32 off, t0, v0, v1;
                 v8i r;                       // the record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
-                asm volatile("s_mov_b32 s67, %[idx]\n"
+                asm volatile("s_mov_b64 %[exec0], exec\n\t"
+                             "s_mov_b32 s67, %[idx]\n"
                              "1:\n\t"
                              "s_lshl_b32 %[off], s67, 5\n\t"                 // s67: the node to fetch, then its skip link
                              "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "v_cmpx_lt_f32_e32 vcc, s66, %[hz]\n\t"
                              "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
                              "s_cbranch_execnz 2f\n\t"                     // somebody overlaps
-                             "s_mov_b64 exec, -1\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
                              "s_cmp_lg_u32 s67, -1\n\t"                    // nobody: follow the skip link
                              "s_cbranch_scc1 1b\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "2:\n\t"
                              "s_cmp_ge_u32 %[off], %[leaf]\n\t"
                              "s_cbranch_scc1 3f\n\t"
-                             "s_mov_b64 exec, -1\n\t"                      // an internal node: descend (down link) and go on
+                             "s_mov_b64 exec, %[exec0]\n\t"                      // an internal node: descend (down link) and go on
                              "s_mov_b32 s67, s71\n\t"
                              "s_branch 1b\n"
                              "3:\n\t"                                       // a leaf: stage (my id, its id) for the hit lanes
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "v_mov_b32 %[v1], s71\n\t"
                              "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"
                              "s_mov_b32 %[cnt], %[t0]\n\t"
-                             "s_mov_b64 exec, -1\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
                              "s_cmp_lg_u32 s67, -1\n\t"                    // and on along the leaf's skip link
                              "s_cbranch_scc1 1b\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
@@ -496,10 +503,10 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "s_branch 4f\n"
                              "5:\n\t"
                              "s_mov_b64 %[hits], exec\n\t"
-                             "s_mov_b64 exec, -1\n"
+                             "s_mov_b64 exec, %[exec0]\n"
                              "4:"
                              : [idx] "+s"(idx), [cnt] "+s"(sink.count), [hits] "=s"(hits), [off] "=&s"(off), [t0] "=&s"(t0),
-                               [v0] "=&v"(v0), [v1] "=&v"(v1), "={s[64:71]}"(r)
+                               [v0] "=&v"(v0), [v1] "=&v"(v1), [exec0] "=&s"(exec0), "=&{s[64:71]}"(r)
                              : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [capw] "s"((u32)CAPW), [buf] "s"(buf_lds),
                                [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
                              : "vcc", "scc", "memory");

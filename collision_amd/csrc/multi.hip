@@ -68,32 +68,51 @@ __global__ __launch_bounds__(256) void k_unpack_radii(const typename MT<T>::V4 *
 // the scene, empty ones inverted); they stay on the device (straight out of the AABB all-gather): no host
 // round trip.
 struct PeerList { int q[8]; int n; };
+// One global counter per list cannot take an atomic per wave: a single address retires ~88 atomics/us on this part,
+// and with most waves holding a hit or two the first version of this kernel spent 0.3-0.4 ms there at 2 M owned
+// spheres (1.1-1.5 ms with the hash partition, where every sphere is selected).  So a block takes SEL_ROWS rows per
+// thread, remembers the outcome of its box tests in registers (a bit per row and peer), and reserves its share of
+// each list with ONE atomic per block and peer after a block scan of the hit counts.
+constexpr int SEL_ROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *__restrict__ rows, u32 n,
                                                        const typename MT<T>::V4 *__restrict__ boxes, PeerList pl, u32 stride,
                                                        u32 *__restrict__ lists, u32 *__restrict__ counts) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    typename MT<T>::V4 c;
-    c.x = c.y = c.z = c.w = (T)0;
-    if (i < n) c = rows[i];
-    const u32 lane = lane_id();
+    typedef typename MT<T>::V4 V4;
+    __shared__ u32 s_warp[4];
+    __shared__ u32 s_base;
+    const u32 tid = threadIdx.x;
+    const u32 base = blockIdx.x * (256u * SEL_ROWS);
+    V4 c[SEL_ROWS];
+#pragma unroll
+    for (int j = 0; j < SEL_ROWS; j++) {
+        const u32 i = base + j * 256u + tid;
+        if (i < n) c[j] = rows[i];
+        else { c[j].x = c[j].y = c[j].z = (T)NAN; c[j].w = (T)0; }      // (NaN: overlaps nothing)
+    }
     for (int k = 0; k < pl.n; k++) {
-        bool hit = false;
-        const typename MT<T>::V4 *region = boxes + 2 * COL_REGION_BOXES * pl.q[k];      // wave-uniform
+        const V4 *region = boxes + 2 * COL_REGION_BOXES * pl.q[k];      // wave-uniform
+        u32 mask = 0;
 #pragma unroll
         for (int o = 0; o < COL_REGION_BOXES; o++) {
-            const typename MT<T>::V4 lo = region[2 * o], hi = region[2 * o + 1];
-            hit |= c.x + c.w > lo.x && c.x - c.w < hi.x && c.y + c.w > lo.y && c.y - c.w < hi.y &&
-                   c.z + c.w > lo.z && c.z - c.w < hi.z;                      // strict, as collision.cl:164-166
+            const V4 lo = region[2 * o], hi = region[2 * o + 1];
+#pragma unroll
+            for (int j = 0; j < SEL_ROWS; j++) {
+                const bool hit = c[j].x + c[j].w > lo.x && c[j].x - c[j].w < hi.x && c[j].y + c[j].w > lo.y &&
+                                 c[j].y - c[j].w < hi.y && c[j].z + c[j].w > lo.z && c[j].z - c[j].w < hi.z;   // strict, as collision.cl:164-166
+                mask |= (u32)hit << j;
+            }
         }
-        hit = hit && i < n;
-        const u64 hits = __ballot(hit);
-        if (!hits) continue;
-        const int leader = (int)__builtin_ctzll(hits);
-        u32 base = 0;
-        if ((int)lane == leader) base = atomicAdd(&counts[k], (u32)__popcll(hits));
-        base = __shfl(base, leader, COL_WAVE);
-        if (hit) lists[(uint64_t)k * stride + base + mbcnt(hits)] = i;
+        u32 total;
+        const u32 before = block_excl_scan<256>((u32)__popc(mask), s_warp, &total);
+        if (total == 0) continue;                                        // (block-uniform)
+        if (tid == 0) s_base = atomicAdd(&counts[k], total);
+        __syncthreads();
+        u32 pos = s_base + before;
+        __syncthreads();                                                 // (s_base is reused by the next peer)
+#pragma unroll
+        for (int j = 0; j < SEL_ROWS; j++)
+            if ((mask >> j) & 1u) lists[(uint64_t)k * stride + pos++] = base + j * 256u + tid;
     }
 }
 
@@ -766,8 +785,8 @@ int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const v
     pl.n = n_peers;
     for (int k = 0; k < 8; k++) pl.q[k] = k < n_peers ? peers[k] : -1;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_select_multi<float><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts)),
-                 (k_select_multi<double><<<dim3(blocks_for(n)), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts)));
+    COL_BY_COORD((k_select_multi<float><<<dim3((unsigned)col_ceil_div(n, 256 * SEL_ROWS)), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts)),
+                 (k_select_multi<double><<<dim3((unsigned)col_ceil_div(n, 256 * SEL_ROWS)), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts)));
     COL_LAUNCH_OK();
     return COL_OK;
 }

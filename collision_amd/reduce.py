@@ -38,16 +38,17 @@ def _parse_init(text, dtype):
         return float("inf"), 0
     if text == "-INFINITY":
         return float("-inf"), 0
-    value = float(text)           # ValueError for anything that is not a number
     base = np.dtype(dtype).base
     if base.kind not in "ui":
-        return value, None
+        return float(text), None  # ValueError for anything that is not a number
     try:
-        exact = int(text, 0)
+        exact = int(text, 0)      # decimal, 0x..., 0b...: as C spells integer literals
     except ValueError:
+        value = float(text)
         if value != int(value):
             raise ValueError("Initial value {} is not an integer ({} accumulator)".format(text, base))
         exact = int(value)
+    value = float(exact)
     info = np.iinfo(base)
     if not info.min <= exact <= info.max:
         raise ValueError("Initial value {} outside the range of {}".format(text, base))

@@ -1,0 +1,58 @@
+/* Analysis only (not product, not a test): simulates the packet walk of csrc/bvh.hip's phase 2 on a tree built by
+ * the oracle, with and without "leaf blocks" (a hit node covering <= B leaves is tested leaf by leaf instead of being
+ * descended into).  Counts steps per packet.  Built and driven by tests/analysis/sim_packet_walk.py. */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { uint32_t parent, right_edge, data[2]; } node_t;
+
+/* bounds: (2n-1) x 2 x 4 floats.  out[0..5] = steps, descents, leaf steps, leaf hits(lane-pairs), blocks, block leaves */
+void sim_walk(const node_t *nodes, const float *bounds, uint32_t n, int B, uint64_t *out) {
+    const uint32_t nn = 2 * n - 1, leaf0 = n - 1, END = 0xFFFFFFFFu;
+    uint32_t *skip = malloc(4ull * nn), *lo = malloc(4ull * nn), *cnt = malloc(4ull * nn), *stack = malloc(4ull * 128);
+    /* preorder from the root: skip links; post-order for (lo, cnt) via the Karras layout: node range = [min(i, other), right_edge] */
+    skip[0] = END;
+    int sp = 0; stack[sp++] = 0;
+    /* iterative DFS; depth <= 64 + ... use heap stack sized nn to be safe */
+    free(stack); stack = malloc(4ull * nn); sp = 0; stack[sp++] = 0;
+    while (sp) {
+        uint32_t x = stack[--sp];
+        if (x >= leaf0) continue;
+        uint32_t a = nodes[x].data[0], b = nodes[x].data[1];
+        skip[a] = b; skip[b] = skip[x];
+        stack[sp++] = a; stack[sp++] = b;
+    }
+    /* ranges: leaves first, then internal nodes bottom-up by repeated passes is O(depth*n); instead compute via right_edge and
+     * leftmost leaf by walking down-left (cheap enough: average depth ~ log n) */
+    for (uint32_t x = 0; x < nn; x++) {
+        uint32_t y = x;
+        while (y < leaf0) y = nodes[y].data[0];
+        lo[x] = y - leaf0;
+        cnt[x] = (x >= leaf0 ? (x - leaf0) : nodes[x].right_edge) - lo[x] + 1;
+    }
+    memset(out, 0, 8 * 8);
+    const uint32_t npackets = (n + 63) / 64;
+    for (uint32_t p = 0; p < npackets; p++) {
+        const uint32_t q0 = p * 64, q1 = (q0 + 64 < n ? q0 + 64 : n);
+        uint32_t idx = skip[leaf0 + q1 - 1];
+        while (idx != END) {
+            const float *r = bounds + 8ull * idx;
+            int any = 0; uint64_t hits = 0;
+            for (uint32_t q = q0; q < q1; q++) {
+                const float *b = bounds + 8ull * (leaf0 + q);
+                int h = b[4] > r[0] && b[0] < r[4] && b[5] > r[1] && b[1] < r[5] && b[6] > r[2] && b[2] < r[6];
+                any |= h; hits += h;
+            }
+            out[0]++;
+            uint32_t next = skip[idx];
+            if (any) {
+                if (idx >= leaf0) { out[2]++; out[3] += hits; }
+                else if (B > 0 && cnt[idx] <= (uint32_t)B) { out[4]++; out[5] += cnt[idx]; }
+                else { out[1]++; next = nodes[idx].data[0]; }
+            }
+            idx = next;
+        }
+    }
+    free(skip); free(lo); free(cnt); free(stack);
+}

@@ -203,3 +203,81 @@ def test_region_boxes(hip_env, oracle, dt, n, with_range):
         np.testing.assert_array_equal(got[o, 0, :3], sel[:, :3].min(axis=0) - rmax)
         np.testing.assert_array_equal(got[o, 1, :3], sel[:, :3].max(axis=0) + rmax)
     assert (got[:, :, 3] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n,n_peers,slot", [(1, 1, 16), (5000, 3, 4096), (70001, 4, 512), (300000, 8, 300000)])
+def test_halo_select_pack_and_ghost_queries(hip_env, oracle, dt, n, n_peers, slot):
+    """The halo branch's device steps in isolation: col_select_overlap_multi (lists = the owned spheres overlapping
+    any of a peer's eight region boxes; one reservation per block and peer), col_pack_slots (header = full length,
+    then min(length, slot) records) and col_traverse_ghost_slots (the received records as queries against a tree:
+    every (ghost, local) AABB overlap, no position pruning) against NumPy."""
+    from collision_amd.collision import Collider
+    from collision_amd.misc import roundUp
+    ctx, cq = hip_env
+    cb = np.dtype(dt).itemsize
+    rw = cb + 1
+    rng = np.random.RandomState(n + n_peers)
+    rows = _rows(rng, n, dt)
+    gids = rng.permutation(1 << 22)[:n].astype(np.uint32)
+    world = n_peers + 2
+    boxes = np.zeros((world, REGION_BOXES, 2, 4), dt)
+    boxes[:, :, 0, :3], boxes[:, :, 1, :3] = np.inf, -np.inf              # empty octants
+    for q in range(world):
+        for o in rng.choice(REGION_BOXES, size=3, replace=False):
+            lo = rng.uniform(0, 0.9, size=3)
+            boxes[q, o, 0, :3], boxes[q, o, 1, :3] = lo, lo + rng.uniform(0.01, 0.25, size=3)
+    peers = list(rng.choice(world, size=n_peers, replace=False))
+    rows_buf, gids_buf, boxes_buf = upload(ctx, rows), upload(ctx, gids), upload(ctx, boxes)
+    lists, counts = hip.Buffer(ctx, 8 * n * 4), upload(ctx, np.zeros(8, np.uint32))
+    call.col_select_overlap_multi(cq.stream, rows_buf.ptr, n, boxes_buf.ptr, (C.c_int * n_peers)(*peers), n_peers, n,
+                                  lists.ptr, counts.ptr, cb)
+    got_counts = download(cq, counts, np.uint32, 8)
+    got_lists = download(cq, lists, np.uint32, (8, n))
+    lo3, hi3 = rows[:, :3] - rows[:, 3:4], rows[:, :3] + rows[:, 3:4]
+    want = []
+    for k, q in enumerate(peers):
+        hit = np.zeros(n, bool)
+        for b in boxes[q]:
+            hit |= ((hi3 > b[0, :3]) & (lo3 < b[1, :3])).all(axis=1)
+        want.append(np.nonzero(hit)[0])
+        assert got_counts[k] == len(want[k])
+        np.testing.assert_array_equal(np.sort(got_lists[k, :len(want[k])]), want[k])
+    # slots
+    send = upload(ctx, np.full(n_peers * (slot + 1) * rw, 0xCDCDCDCD, np.uint32))
+    call.col_pack_slots(cq.stream, rows_buf.ptr, gids_buf.ptr, lists.ptr, n, counts.ptr, n_peers, min(max(n, 1), slot),
+                        send.ptr, n_peers * (slot + 1), slot, cb)
+    rec = download(cq, send, np.uint32, (n_peers, slot + 1, rw))
+    for k in range(n_peers):
+        cnt = min(len(want[k]), slot)
+        assert rec[k, 0, 0] == len(want[k]) and not rec[k, 0, 1:].any()
+        src = got_lists[k, :cnt]
+        np.testing.assert_array_equal(rec[k, 1:1 + cnt, :rw - 1], rows[src].view(np.uint32).reshape(cnt, rw - 1))
+        np.testing.assert_array_equal(rec[k, 1:1 + cnt, rw - 1], gids[src])
+    # the packed slots as ghosts against a tree over OTHER spheres
+    m = 20000
+    local = _rows(np.random.RandomState(99), m, dt)
+    local[:, 3] *= 4
+    lg = np.arange(m, dtype=np.uint32) + 5000000
+    col = Collider(ctx, m, 16, 64, dt)
+    nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, 8)
+    col.get_collisions(cq, upload(ctx, local), upload(ctx, np.ascontiguousarray(local[:, 3])), nb, None, 0)
+    cap = 1 << 22
+    pairs, counter, flags = hip.Buffer(ctx, cap * 8), upload(ctx, np.zeros(1, np.uint32)), upload(ctx, np.zeros(4, np.uint32))
+    call.col_traverse_ghost_slots(cq.stream, send.ptr, n_peers, slot, col._bounds_buf.ptr, m, upload(ctx, lg).ptr,
+                                  pairs.ptr, counter.ptr, cap, flags.ptr, cb)
+    count = int(download(cq, counter, np.uint32, 1)[0])
+    got = download(cq, pairs, np.uint32, (min(count, cap), 2))
+    llo, lhi = local[:, :3] - local[:, 3:4], local[:, :3] + local[:, 3:4]
+    expect = []
+    n_ghosts = 0
+    for k in range(n_peers):
+        cnt = min(len(want[k]), slot)
+        n_ghosts += cnt
+        for s in got_lists[k, :cnt]:
+            hit = ((hi3[s] > llo) & (lo3[s] < lhi)).all(axis=1)
+            expect += [(int(gids[s]), int(lg[j])) for j in np.nonzero(hit)[0]]
+    assert count == len(expect) <= cap
+    assert sorted(map(tuple, got.tolist())) == sorted(expect)
+    f = download(cq, flags, np.uint32, 4)
+    assert f[0] == max([len(w) for w in want] + [0]) and f[1] == n_ghosts
