@@ -108,6 +108,7 @@ _PROTOS = {
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
+    "col_debug_leaf_blocks": (C.c_int, [C.c_float]),
     "col_debug_radix": (C.c_int, [C.c_int]),
     "col_debug_radix_stamps": (None, [C.c_void_p, C.c_int]),
     "col_debug_radix_tile": (None, [C.c_int]),

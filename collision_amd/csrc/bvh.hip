@@ -9,7 +9,9 @@
 // stack and touches 5 cache lines per step (node, two child nodes, two child bounds).  Here
 // the unused lane w of every node's Bound carries two links written at build time --
 //     min.w = "skip": the node that follows this subtree in depth-first order,
-//     max.w = left child (internal) or sphere id (leaf)
+//     max.w = "down": left child (internal) or sphere id (leaf); in trees built by lbvh.hip a DENSE internal node
+//             over at most 16 leaves carries a LEAF BLOCK mark instead (col_common.h: first leaf and count) and
+//             the packet walk tests its leaves at once instead of descending
 // -- so a traversal step is ONE 32-byte record (two float4 loads) and needs no stack.  A
 // query for sorted leaf q only has to report leaves p > q (collision.cl:199-200), and those
 // are exactly the subtrees hanging to the right of q's root path, i.e. the chain
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_build(const u32 *__restrict__ codes, co
     nodes[child_b].parent = i;
     if (bounds) {
         link_store(bounds, 2ull * i, hi + 1 < n ? right_child_at(codes, n, hi + 1) : END);
-        link_store(bounds, 2ull * i + 1, child_a);
+        link_store(bounds, 2ull * i + 1, child_a);      // (no leaf-block marks here: they need the boxes, see lbvh.hip)
     }
 }
 
@@ -304,7 +306,9 @@ template <typename T, bool MAX> __device__ __forceinline__ T wave_min_max(T v) {
 
 // STATS: count phase-2 steps for col_traverse_stats (diagnostics); the production instance carries
 // no counters.  VEC: record loads as vector loads at a uniform address (ablation).
-template <typename T, bool STATS, bool VEC, bool OFF32>
+// WALK: 0 = the generic phase-2 loop; 1 = the asm walk with the in-loop leaf-block test (needs 32-bit record offsets);
+// 2 = the asm walk without it (marked nodes are entered through their leaf chain): the A/B reference of col_debug_traverse(128)
+template <typename T, bool STATS, bool VEC, int WALK>
 __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode) {
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const u32 lane = lane_id();
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));     // scalar: packet, q0, pos stay in SGPRs
     const u32 leaf_start = n - 1;
+    const bool marks = n <= COL_LEAF_BLOCK_MAX_N;      // internal nodes over <= 16 leaves carry leaf-block marks
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
     const u32 npackets = (n + 63) / 64;
@@ -448,31 +453,77 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
         if (mode & 2) idx = END;
-        if constexpr (sizeof(T) == 4 && OFF32 && !VEC) {
+        if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
             // (the asm walk narrows EXEC with v_cmpx and restores the mask it found on entry -- the full wave here:
             // 1024-thread blocks, wave-uniform control flow above)
-            while (idx != END) {
+            //
+            // LEAF BLOCKS (col_common.h): a hit internal node whose `down` link carries the mark covers <= 16
+            // consecutive leaves.  Descending would cost ~2 DEPENDENT record fetches per leaf; instead its leaf records
+            // -- consecutive 32-byte records from a known offset -- are fetched by independent scalar loads, double
+            // buffered in s[72:79] / s[80:87] (the next candidate is in flight while the current one is compared), and
+            // tested with the same v_cmpx chain; hits are staged exactly like a hit leaf's.  BASELINE config 3: 670 ->
+            // 170 walk steps per packet + 420 block candidates (tests/analysis/sim_packet_walk.py).
+            // State across an exit to the pair sink (staging area full): bcnt = candidates of the current block still to
+            // test (0 = not inside a block), boff = byte offset of the next one; idx = where the walk goes on.
+            u32 bcnt = 0, boff = 0;
+            while (idx != END || bcnt != 0) {      // (an interrupted block is finished even when the chain ends behind it)
                 u64 hits, exec0;
-                u32 off, t0, v0, v1;
-                v8i r;                       // the record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
+                u32 off, t0, v0, v1, pid;
+                v8i r;                       // the node record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
+#define COL_CMPX6(LX, LY, LZ, HX, HY, HZ)                                         \
+                             "v_cmpx_lt_f32_e32 vcc, " LX ", %[hx]\n\t"           /* lo.x < my hi.x */ \
+                             "v_cmpx_gt_f32_e32 vcc, " HX ", %[lx]\n\t"           /* hi.x > my lo.x */ \
+                             "v_cmpx_lt_f32_e32 vcc, " LY ", %[hy]\n\t"                              \
+                             "v_cmpx_gt_f32_e32 vcc, " HY ", %[ly]\n\t"                              \
+                             "v_cmpx_lt_f32_e32 vcc, " LZ ", %[hz]\n\t"                              \
+                             "v_cmpx_gt_f32_e32 vcc, " HZ ", %[lz]\n\t"
+                // stage (my id, ID) for the lanes in EXEC; FULL: label to leave through when the staging area is full
+#define COL_STAGE(ID, FULL)                                                       \
+                             "s_bcnt1_i32_b64 %[t0], exec\n\t"                                      \
+                             "s_add_u32 %[t0], %[cnt], %[t0]\n\t"                                   \
+                             "s_cmp_gt_u32 %[t0], %[capw]\n\t"                                      \
+                             "s_cbranch_scc1 " FULL "\n\t"                                          \
+                             "v_mbcnt_lo_u32_b32 %[v0], exec_lo, 0\n\t"                             \
+                             "v_mbcnt_hi_u32_b32 %[v0], exec_hi, %[v0]\n\t"                         \
+                             "v_add_u32 %[v0], %[cnt], %[v0]\n\t"                                   \
+                             "v_lshl_add_u32 %[v0], %[v0], 3, %[buf]\n\t"                           \
+                             "v_mov_b32 %[v1], " ID "\n\t"                                          \
+                             "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"                     \
+                             "s_mov_b32 %[cnt], %[t0]\n\t"
+                // one candidate of a leaf block in buffer CUR (LX.. its registers), the next one prefetched into NXT
+#define COL_CAND(LX, LY, LZ, HX, HY, HZ, ID, NXT, SKIPLBL, FULLLBL)               \
+                             "s_waitcnt lgkmcnt(0)\n\t"                                             \
+                             "s_cmp_lt_u32 %[bcnt], 2\n\t"                                          \
+                             "s_cbranch_scc1 " SKIPLBL "f\n\t"                                      \
+                             "s_add_u32 %[t0], %[boff], 32\n\t"                                     \
+                             "s_load_dwordx8 " NXT ", %[base], %[t0]\n"                              \
+                             SKIPLBL ":\n\t"                                                        \
+                             COL_CMPX6(LX, LY, LZ, HX, HY, HZ)                                        \
+                             "s_sub_u32 %[bcnt], %[bcnt], 1\n\t"                                    \
+                             "s_add_u32 %[boff], %[boff], 32\n\t"                                   \
+                             "s_cbranch_execz " SKIPLBL "0f\n\t"                                    \
+                             "s_mov_b32 %[pid], " ID "\n\t"                                         \
+                             COL_STAGE(ID, FULLLBL)                                                   \
+                             SKIPLBL "0:\n\t"                                                       \
+                             "s_mov_b64 exec, %[exec0]\n\t"                                         \
+                             "s_cmp_eq_u32 %[bcnt], 0\n\t"                                          \
+                             "s_cbranch_scc1 8b\n\t"
                 asm volatile("s_mov_b64 %[exec0], exec\n\t"
-                             "s_mov_b32 s67, %[idx]\n"
+                             "s_mov_b32 s43, %[idx]\n\t"
+                             "s_cmp_lg_u32 %[bcnt], 0\n\t"                // inside a leaf block (the sink flushed): go on with it
+                             "s_cbranch_scc1 6f\n"
                              "1:\n\t"
-                             "s_lshl_b32 %[off], s67, 5\n\t"                 // s67: the node to fetch, then its skip link
-                             "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"
+                             "s_lshl_b32 %[off], s43, 5\n\t"                 // s43: the node to fetch, then its skip link
+                             "s_load_dwordx8 s[40:47], %[base], %[off]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
-                             "v_cmpx_lt_f32_e32 vcc, s64, %[hx]\n\t"        // lo.x < my hi.x
-                             "v_cmpx_gt_f32_e32 vcc, s68, %[lx]\n\t"        // hi.x > my lo.x
-                             "v_cmpx_lt_f32_e32 vcc, s65, %[hy]\n\t"
-                             "v_cmpx_gt_f32_e32 vcc, s69, %[ly]\n\t"
-                             "v_cmpx_lt_f32_e32 vcc, s66, %[hz]\n\t"
-                             "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
+                             COL_CMPX6("s40", "s41", "s42", "s44", "s45", "s46")
                              "s_cbranch_execnz 2f\n\t"                     // somebody overlaps
-                             "s_mov_b64 exec, %[exec0]\n\t"
-                             "s_cmp_lg_u32 s67, -1\n\t"                    // nobody: follow the skip link
+                             "s_mov_b64 exec, %[exec0]\n"
+                             "8:\n\t"
+                             "s_cmp_lg_u32 s43, -1\n\t"                    // nobody (or the leaf / block is done): follow the skip link
                              "s_cbranch_scc1 1b\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
                              "s_mov_b64 %[hits], 0\n\t"
@@ -480,14 +531,89 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "2:\n\t"
                              "s_cmp_ge_u32 %[off], %[leaf]\n\t"
                              "s_cbranch_scc1 3f\n\t"
-                             "s_mov_b64 exec, %[exec0]\n\t"                      // an internal node: descend (down link) and go on
-                             "s_mov_b32 s67, s71\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_bitcmp1_b32 s47, 31\n\t"                  // a leaf block?
+                             "s_cbranch_scc1 7f\n\t"
+                             "s_mov_b32 s43, s47\n\t"                      // an internal node: descend (down link) and go on
                              "s_branch 1b\n"
                              "3:\n\t"                                       // a leaf: stage (my id, its id) for the hit lanes
+                             "s_mov_b32 %[pid], s47\n\t"
+                             COL_STAGE("s47", "5f")
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_branch 8b\n"
+                             "7:\n\t"                                       // a leaf block: count and offset of its first leaf record
+                             "s_and_b32 %[bcnt], s47, 15\n\t"
+                             "s_add_u32 %[bcnt], %[bcnt], 1\n\t"
+                             "s_bfe_u32 %[boff], s47, 0x1b0004\n\t"        // bits 4..30: the first leaf
+                             "s_lshl_b32 %[boff], %[boff], 5\n\t"
+                             "s_add_u32 %[boff], %[boff], %[leaf]\n"
+                             "6:\n\t"
+                             "s_load_dwordx8 s[48:55], %[base], %[boff]\n"
+                             "9:\n\t"
+                             COL_CAND("s48", "s49", "s50", "s52", "s53", "s54", "s55", "s[56:63]", "11", "5f")
+                             COL_CAND("s56", "s57", "s58", "s60", "s61", "s62", "s63", "s[48:55]", "21", "5f")
+                             "s_branch 9b\n"
+                             "5:\n\t"                                       // the staging area is full: let the sink flush it
+                             "s_mov_b64 %[hits], exec\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n"                      // (a prefetched candidate may still be in flight)
+                             "4:"
+                             : [idx] "+s"(idx), [cnt] "+s"(sink.count), [bcnt] "+s"(bcnt), [boff] "+s"(boff), [hits] "=s"(hits),
+                               [off] "=&s"(off), [t0] "=&s"(t0), [pid] "=&s"(pid), [v0] "=&v"(v0), [v1] "=&v"(v1),
+                               [exec0] "=&s"(exec0), "=&{s[40:47]}"(r)
+                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [capw] "s"((u32)CAPW), [buf] "s"(buf_lds),
+                               [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
+                             : "vcc", "scc", "memory", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
+                               "s59", "s60", "s61", "s62", "s63");
+#undef COL_CAND
+#undef COL_STAGE
+#undef COL_CMPX6
+                if (!hits) break;                                           // the chain ended (idx == END)
+                sink.emit(hits, qid, pid);                                  // the staging area was full: flush, then stage
+                idx = (u32)r[3];                                            // and on: the rest of the block (bcnt), then the skip link
+            }
+        } else if constexpr (sizeof(T) == 4 && WALK == 2 && !VEC) {
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            const char *rows_b = reinterpret_cast<const char *>(rows);
+            const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;
+            while (idx != END) {
+                u64 hits, exec0;
+                u32 off, t0, v0, v1;
+                v8i r;
+                asm volatile("s_mov_b64 %[exec0], exec\n\t"
+                             "s_mov_b32 s67, %[idx]\n"
+                             "1:\n\t"
+                             "s_lshl_b32 %[off], s67, 5\n\t"
+                             "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_cmpx_lt_f32_e32 vcc, s64, %[hx]\n\t"
+                             "v_cmpx_gt_f32_e32 vcc, s68, %[lx]\n\t"
+                             "v_cmpx_lt_f32_e32 vcc, s65, %[hy]\n\t"
+                             "v_cmpx_gt_f32_e32 vcc, s69, %[ly]\n\t"
+                             "v_cmpx_lt_f32_e32 vcc, s66, %[hz]\n\t"
+                             "v_cmpx_gt_f32_e32 vcc, s70, %[lz]\n\t"
+                             "s_cbranch_execnz 2f\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_cmp_lg_u32 s67, -1\n\t"
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 %[idx], -1\n\t"
+                             "s_mov_b64 %[hits], 0\n\t"
+                             "s_branch 4f\n"
+                             "2:\n\t"
+                             "s_cmp_ge_u32 %[off], %[leaf]\n\t"
+                             "s_cbranch_scc1 3f\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_mov_b32 s67, s71\n\t"                      // descend (down link) ...
+                             "s_bitcmp1_b32 s71, 31\n\t"
+                             "s_cbranch_scc0 1b\n\t"
+                             "s_bfe_u32 s67, s71, 0x1b0004\n\t"            // ... or, a leaf block: on through its leaf chain
+                             "s_add_u32 s67, s67, %[leafidx]\n\t"
+                             "s_branch 1b\n"
+                             "3:\n\t"
                              "s_bcnt1_i32_b64 %[t0], exec\n\t"
                              "s_add_u32 %[t0], %[cnt], %[t0]\n\t"
                              "s_cmp_gt_u32 %[t0], %[capw]\n\t"
-                             "s_cbranch_scc1 5f\n\t"                        // the staging area is full: let the sink flush it
+                             "s_cbranch_scc1 5f\n\t"
                              "v_mbcnt_lo_u32_b32 %[v0], exec_lo, 0\n\t"
                              "v_mbcnt_hi_u32_b32 %[v0], exec_hi, %[v0]\n\t"
                              "v_add_u32 %[v0], %[cnt], %[v0]\n\t"
@@ -496,7 +622,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"
                              "s_mov_b32 %[cnt], %[t0]\n\t"
                              "s_mov_b64 exec, %[exec0]\n\t"
-                             "s_cmp_lg_u32 s67, -1\n\t"                    // and on along the leaf's skip link
+                             "s_cmp_lg_u32 s67, -1\n\t"
                              "s_cbranch_scc1 1b\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
                              "s_mov_b64 %[hits], 0\n\t"
@@ -507,12 +633,13 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "4:"
                              : [idx] "+s"(idx), [cnt] "+s"(sink.count), [hits] "=s"(hits), [off] "=&s"(off), [t0] "=&s"(t0),
                                [v0] "=&v"(v0), [v1] "=&v"(v1), [exec0] "=&s"(exec0), "=&{s[64:71]}"(r)
-                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [capw] "s"((u32)CAPW), [buf] "s"(buf_lds),
-                               [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
+                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [leafidx] "s"(leaf_start), [capw] "s"((u32)CAPW),
+                               [buf] "s"(buf_lds), [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx),
+                               [ly] "v"(ly), [lz] "v"(lz)
                              : "vcc", "scc", "memory");
-                if (!hits) break;                                           // the chain ended (idx == END)
-                sink.emit(hits, qid, (u32)r[7]);                             // (the staging area was full: flush, then stage)
-                idx = (u32)r[3];                                            // and on along the leaf's skip link
+                if (!hits) break;
+                sink.emit(hits, qid, (u32)r[7]);
+                idx = (u32)r[3];
             }
         } else {
             auto test = [&](const V4 &a, const V4 &b) -> u64 {
@@ -537,7 +664,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                 u32 next = skip;
                 if (hits) {
                     if (is_leaf) { sink.emit(hits, qid, down); if (STATS) leaf_hits++; }
-                    else { next = down; if (STATS) descents++; }
+                    else { next = descend_link(down, leaf_start, marks); if (STATS) descents++; }      // (a leaf block: on through its leaves)
                 }
                 idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
@@ -583,6 +710,7 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
     __shared__ u32 s_base;
     const u32 lane = lane_id(), w = threadIdx.x / 64;
     const u32 leaf_start = n - 1;
+    const bool marks = n <= COL_LEAF_BLOCK_MAX_N;
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
     PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
     const u32 npackets = (n + 63) / 64;
@@ -607,7 +735,7 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
                 const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
                 const bool leaf = idx >= leaf_start;
                 hit = overlap && leaf;
-                idx = (overlap && !leaf) ? down : skip;
+                idx = (overlap && !leaf) ? descend_link(down, leaf_start, marks) : skip;
             }
             const u64 hits = __ballot(hit);
             if (hits) sink.emit(hits, qid, down);
@@ -648,10 +776,11 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
     const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
     if ((g_traverse_variant & 255) == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
-    else if (st) k_traverse<T, true, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (g_traverse_variant & 2) k_traverse<T, false, true, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (off32) k_traverse<T, false, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else k_traverse<T, false, false, false><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (st) k_traverse<T, true, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (g_traverse_variant & 2) k_traverse<T, false, true, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32 && (g_traverse_variant & 128)) k_traverse<T, false, false, 2><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }

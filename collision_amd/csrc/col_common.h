@@ -104,6 +104,22 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *warp_sums, u32 *total
     *total = tot;
     return base + incl - v;
 }
+// ---- traversal links (lane w of every node's Bound record, bvh.hip): `skip`, and `down` = left child (internal
+// node) or sphere id (leaf).  LEAF BLOCKS: lbvh.hip lets an internal node that covers at most COL_LEAF_BLOCK
+// consecutive sorted leaves [lo, hi] AND is dense (its box is at most a few leaf boxes wide on every axis, so a query
+// that meets the node meets a good part of its leaves) carry COL_LINK_MARK | lo << 4 | (hi - lo) in `down` instead:
+// a walk that hits it tests its leaves -- consecutive 32-byte records from leaf_start + lo -- straight away instead
+// of descending (two dependent record fetches per leaf).  Only written while lo fits 27 bits
+// (n <= COL_LEAF_BLOCK_MAX_N); larger trees carry plain child links and walkers must not interpret bit 31.
+#define COL_LEAF_BLOCK 16u
+#define COL_LINK_MARK 0x80000000u
+#define COL_LEAF_BLOCK_MAX_N (1u << 27)
+__device__ __forceinline__ u32 block_link(u32 lo, u32 hi) { return COL_LINK_MARK | (lo << 4) | (hi - lo); }
+// where a walk goes on from a hit internal node with link `down`: its left child, or (leaf block) its first leaf --
+// the skip links of the leaves then lead through the whole block (nested blocks are entered the same way)
+__device__ __forceinline__ u32 descend_link(u32 down, u32 leaf_start, bool marks) {
+    return (marks && (down & COL_LINK_MARK)) ? leaf_start + ((down >> 4) & 0x7FFFFFFu) : down;
+}
 // ---- 30-bit Morton codes (collision.cl:14-31); shared by morton.hip and multi.hip ----
 __device__ __forceinline__ u32 expand_bits(u32 v) {   // collision.cl:14-20
     v = (v * 0x00010001u) & 0xFF0000FFu;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                                              const T *__restrict__ packed,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial,
-                                             T *__restrict__ tab1, u32 n, typename ChunkDiag<DIAG>::T diag) {
+                                             T *__restrict__ tab1, u32 n, T block_k, typename ChunkDiag<DIAG>::T diag) {
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     typedef typename BT<T>::V4 V4;
     __shared__ ChunkLds<T> lds;
@@ -329,7 +329,19 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                 done = true;
             }
         }
-        record_store(bounds, (uint64_t)i, box, skip, child_a);
+        // leaf block (col_common.h): a small DENSE node -- on every axis at most block_k times as wide as its first
+        // leaf -- is marked for the packet walk.  Sparse scenes (BASELINE config 2: leaf boxes a fifth of the
+        // spacing) get no marks and walk as before; where spheres overlap in heaps (config 3) nearly every node
+        // of <= 16 leaves qualifies.
+        u32 down = child_a;
+        if (hi - lo < COL_LEAF_BLOCK && n <= COL_LEAF_BLOCK_MAX_N && block_k > (T)0) {
+            const Box<T> first = soa_get(lds.leaf, (int)(lo - c0));
+            bool dense = true;
+#pragma unroll
+            for (int k = 0; k < 3; k++) dense = dense && (box.hi[k] - box.lo[k]) <= block_k * (first.hi[k] - first.lo[k]);
+            if (dense) down = block_link(lo, hi);
+        }
+        record_store(bounds, (uint64_t)i, box, skip, down);
     } else {
         links_store(bounds, (uint64_t)i, skip, child_a);
         // this chunk's half of the range: suffix from i (forward) or prefix up to i (backward)
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
 }
 
 int g_dbg = 0;         // process-wide diagnostics switch (col_debug_lbvh); see include/collision_hip.h
+float g_block_k = 3.0f;   // leaf-block density criterion (col_debug_leaf_blocks): node width <= k x leaf width; 0 = no marks
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
@@ -428,13 +441,13 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     const u32 nchunks = L.count[0];
     if (g_dbg)
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                                    (T *)tabs.t[0], n, ChunkDiagOn{g_dbg});
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg});
     else if (n < (1u << 30))
         k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                                     (T *)tabs.t[0], n, ChunkDiagOff{});
+                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     else
         k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
-                                                                     (T *)tabs.t[0], n, ChunkDiagOff{});
+                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
     int lin = -1;
@@ -455,6 +468,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
 extern "C" {
 
 void col_debug_lbvh(int mode) { g_dbg = mode; }
+void col_debug_leaf_blocks(float k) { g_block_k = k; }
 
 size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, coord_bytes).total + 256; }
 

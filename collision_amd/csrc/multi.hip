@@ -152,6 +152,7 @@ __global__ __launch_bounds__(GW * 64) void k_ghost(const typename MT<T>::V4 *__r
     __shared__ uint2 s_buf[GW][GCAP];
     const u32 lane = lane_id(), w = threadIdx.x / 64;
     const u32 leaf_start = n - 1;
+    const bool marks = n <= COL_LEAF_BLOCK_MAX_N;
     uint2 *buf = s_buf[w];
     u32 staged = 0;
     const u32 g = blockIdx.x * (GW * 64) + threadIdx.x;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(GW * 64) void k_ghost(const typename MT<T>::V4 *__r
             const bool overlap = hx > a.x && lx < b.x && hy > a.y && ly < b.y && hz > a.z && lz < b.z;
             const bool leaf = idx >= leaf_start;
             hit = overlap && leaf;
-            idx = (overlap && !leaf) ? down : skip;
+            idx = (overlap && !leaf) ? descend_link(down, leaf_start, marks) : skip;      // (a leaf block: on through its leaves)
         }
         const u64 hits = __ballot(hit);
         if (hits) {

@@ -183,6 +183,8 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
 void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
+void col_debug_leaf_blocks(float k);    /* leaf-block criterion of col_lbvh (process-wide): a node of <= 16 leaves is marked when it is at
+                                         * most k leaf boxes wide on every axis; default 3, 0 = no marks, a huge k = every small node */
 /* The col_debug_* switches are PROCESS-WIDE and unsynchronised: they select separate diagnostics instances of the
  * kernels for every caller in the process (the production instances carry no diagnostics code).  Set them from one
  * thread while no work is in flight; col_collide / col_collide_plan refuse to run under a forced tile class. */

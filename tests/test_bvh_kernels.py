@@ -159,7 +159,26 @@ def test_fused_lbvh_equals_generic_kernels_and_oracle(hip_env, oracle, dt, n):
     na, nb = download(cq, nodes_a, Node, nn), download(cq, nodes_b, Node, nn)
     ba, bb = download(cq, bounds_a, dt, (nn, 2, 4)), download(cq, bounds_b, dt, (nn, 2, 4))
     np.testing.assert_array_equal(na, nb)                  # untouched fields keep the NO_NODE fill in both
-    np.testing.assert_array_equal(ba.view(np.uint8), bb.view(np.uint8))     # boxes AND lane-w links, bit for bit
+    ua, ub = ba.view(np.uint32 if cb == 4 else np.uint64), bb.view(np.uint32 if cb == 4 else np.uint64)
+    np.testing.assert_array_equal(ua[:, :, :3], ub[:, :, :3])               # boxes, bit for bit
+    np.testing.assert_array_equal(ua[:, 0, 3], ub[:, 0, 3])                 # skip links
+    # down links: equal, except where the fused build marked a LEAF BLOCK (a small dense node): the mark must name the
+    # node's own leaf range -- first leaf (leftmost descendant) and count (col_common.h)
+    da, db = ua[:, 1, 3].astype(np.uint64), ub[:, 1, 3].astype(np.uint64)
+    marked = (da != db)
+    assert not marked[n - 1:].any()                                         # never a leaf
+    if marked.any():
+        first = np.arange(nn, dtype=np.int64)
+        for _ in range(64):                                                 # leftmost leaf of every node
+            inner = first < n - 1
+            if not inner.any():
+                break
+            first[inner] = nb["data"][first[inner], 0]
+        lo = first - (n - 1)
+        hi = np.where(np.arange(nn) < n - 1, nb["right_edge"], np.arange(nn) - (n - 1)).astype(np.int64)
+        idx = np.nonzero(marked)[0]
+        assert ((hi[idx] - lo[idx]) < 16).all()
+        np.testing.assert_array_equal(da[idx], 0x80000000 | (lo[idx] << 4) | (hi[idx] - lo[idx]))
     if n >= 2:
         ref_nodes = oracle.build_bvh(codes, ids)
         ref_bounds = oracle.node_bounds(coords, radii, ref_nodes)

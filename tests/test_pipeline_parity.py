@@ -311,3 +311,32 @@ def test_back_to_back_calls_on_a_clustered_scene(oracle, hip_env):
     cq.finish()
     assert pinned.oversize_bucket > 8192
     assert int(hip.read_buffer(cq, outs[1][0], np.uint32, 1)[0]) == ref["count"]
+
+
+@pytest.mark.parametrize("k", [0.0, 1.5, 3.0, 1e30])
+@pytest.mark.parametrize("scene", ["clustered", "identical", "uniform_dense", "tiny_capacity"])
+def test_leaf_blocks_do_not_change_the_result(hip_env, oracle, k, scene):
+    """Leaf blocks (col_common.h: small dense nodes whose leaves the packet walk tests at once instead of descending)
+    are an optimisation of the walk only: with no marks (k = 0), the default criterion, a tight one and every small
+    node marked (k huge) the whole path equals the oracle -- on heaps of overlapping spheres, on identical spheres
+    (every pair collides: the staging area overflows inside blocks), and with a pair buffer that is too small."""
+    from collision_amd._lib import cdll
+    import ctypes
+    lib = cdll()
+    lib.col_debug_leaf_blocks.argtypes = [ctypes.c_float]
+    lib.col_debug_leaf_blocks(ctypes.c_float(k))
+    try:
+        if scene == "clustered":
+            coords, radii = clustered_scene(60000, 0.01, 0.002, "float32")
+            check_against_oracle(oracle, hip_env, coords, radii)
+        elif scene == "identical":
+            coords = np.full((700, 3), 0.25, np.float32)
+            check_against_oracle(oracle, hip_env, coords, np.full(700, 0.01, np.float32))
+        elif scene == "uniform_dense":
+            coords, radii = uniform_scene(30000, 0.03, "float32")
+            check_against_oracle(oracle, hip_env, coords, radii, group_size=256)
+        else:
+            coords, radii = clustered_scene(20000, 0.01, 0.002, "float32")
+            check_against_oracle(oracle, hip_env, coords, radii, capacity=1000)
+    finally:
+        lib.col_debug_leaf_blocks(ctypes.c_float(3.0))
