@@ -454,7 +454,6 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
         if (mode & 2) idx = END;
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
-            typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
             // (the asm walk narrows EXEC with v_cmpx and restores the mask it found on entry -- the full wave here:
@@ -462,17 +461,21 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
             //
             // LEAF BLOCKS (col_common.h): a hit internal node whose `down` link carries the mark covers <= 16
             // consecutive leaves.  Descending would cost ~2 DEPENDENT record fetches per leaf; instead its leaf records
-            // -- consecutive 32-byte records from a known offset -- are fetched by independent scalar loads, double
-            // buffered in s[72:79] / s[80:87] (the next candidate is in flight while the current one is compared), and
-            // tested with the same v_cmpx chain; hits are staged exactly like a hit leaf's.  BASELINE config 3: 670 ->
-            // 170 walk steps per packet + 420 block candidates (tests/analysis/sim_packet_walk.py).
+            // -- consecutive 32-byte records from a known offset -- are fetched by independent 64-byte scalar loads,
+            // three candidates in flight (two in s[40:55] -- the node record is done with once its skip link is saved --
+            // and one in s[56:63]), and tested with the same v_cmpx chain; hits are staged exactly like a hit leaf's.
+            // BASELINE config 3: 670 -> 170 walk steps per packet + 420 block candidates
+            // (tests/analysis/sim_packet_walk.py).  A 64-byte load that starts at a block's last candidate reads 32
+            // bytes beyond it: the next leaf's record, or -- behind the very last record -- the rest of the 64-byte
+            // line that holds it (records are 32-byte aligned and their number is odd), never another page.
+            // SGPR budget: the kernel must stay at <= 80 SGPRs in total -- above that only ONE 16-wave block fits a CU
+            // on this platform (measured: +55 % on the uniform scene from one clobbered high register).
             // State across an exit to the pair sink (staging area full): bcnt = candidates of the current block still to
             // test (0 = not inside a block), boff = byte offset of the next one; idx = where the walk goes on.
             u32 bcnt = 0, boff = 0;
             while (idx != END || bcnt != 0) {      // (an interrupted block is finished even when the chain ends behind it)
-                u64 hits, exec0;
-                u32 off, t0, v0, v1, pid;
-                v8i r;                       // the node record the loop stopped at: (lo.xyz, skip, hi.xyz, down)
+                u64 hits, exec0;             // hits, on exit: the lanes to stage after a flush (0 = the chain ended)
+                u32 pid, v0, v1, bskip;      // pid: scratch inside the asm, the hit candidate's id on exit
 #define COL_CMPX6(LX, LY, LZ, HX, HY, HZ)                                         \
                              "v_cmpx_lt_f32_e32 vcc, " LX ", %[hx]\n\t"           /* lo.x < my hi.x */ \
                              "v_cmpx_gt_f32_e32 vcc, " HX ", %[lx]\n\t"           /* hi.x > my lo.x */ \
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
 #define COL_STAGE(ID, FULL)                                                       \
                              "s_bcnt1_i32_b64 %[t0], exec\n\t"                                      \
                              "s_add_u32 %[t0], %[cnt], %[t0]\n\t"                                   \
-                             "s_cmp_gt_u32 %[t0], %[capw]\n\t"                                      \
+                             "s_cmp_gt_u32 %[t0], 512\n\t"                /* CAPW */                \
                              "s_cbranch_scc1 " FULL "\n\t"                                          \
                              "v_mbcnt_lo_u32_b32 %[v0], exec_lo, 0\n\t"                             \
                              "v_mbcnt_hi_u32_b32 %[v0], exec_hi, %[v0]\n\t"                         \
@@ -493,85 +496,113 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
                              "v_mov_b32 %[v1], " ID "\n\t"                                          \
                              "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"                     \
                              "s_mov_b32 %[cnt], %[t0]\n\t"
-                // one candidate of a leaf block in buffer CUR (LX.. its registers), the next one prefetched into NXT
-#define COL_CAND(LX, LY, LZ, HX, HY, HZ, ID, NXT, SKIPLBL, FULLLBL)               \
-                             "s_waitcnt lgkmcnt(0)\n\t"                                             \
-                             "s_cmp_lt_u32 %[bcnt], 2\n\t"                                          \
-                             "s_cbranch_scc1 " SKIPLBL "f\n\t"                                      \
-                             "s_add_u32 %[t0], %[boff], 32\n\t"                                     \
-                             "s_load_dwordx8 " NXT ", %[base], %[t0]\n"                              \
-                             SKIPLBL ":\n\t"                                                        \
+                // candidate number K (0..3) of the group of four in flight: its registers, then "was it the last one?"
+#define COL_CAND(K, LX, LY, LZ, HX, HY, HZ, ID)                                   \
                              COL_CMPX6(LX, LY, LZ, HX, HY, HZ)                                        \
-                             "s_sub_u32 %[bcnt], %[bcnt], 1\n\t"                                    \
-                             "s_add_u32 %[boff], %[boff], 32\n\t"                                   \
-                             "s_cbranch_execz " SKIPLBL "0f\n\t"                                    \
-                             "s_mov_b32 %[pid], " ID "\n\t"                                         \
-                             COL_STAGE(ID, FULLLBL)                                                   \
-                             SKIPLBL "0:\n\t"                                                       \
+                             "s_cbranch_execz 1" K "f\n\t"                                          \
+                             COL_STAGE(ID, "2" K "f")                                                 \
+                             "1" K ":\n\t"                                                          \
                              "s_mov_b64 exec, %[exec0]\n\t"                                         \
-                             "s_cmp_eq_u32 %[bcnt], 0\n\t"                                          \
-                             "s_cbranch_scc1 8b\n\t"
+                             "s_cmp_eq_u32 %[bcnt], " K " + 1\n\t"                                  \
+                             "s_cbranch_scc1 7f\n\t"
+                // the way out when candidate K found the staging area full: the block goes on behind it after the flush
+#define COL_CAND_FULL(K, ID)                                                      \
+                             "2" K ":\n\t"                                                          \
+                             "s_mov_b32 %[t0], " ID "\n\t"                                          \
+                             "s_sub_u32 %[bcnt], %[bcnt], " K " + 1\n\t"                            \
+                             "s_add_u32 %[boff], %[boff], 32 * (" K " + 1)\n\t"                     \
+                             "s_branch 5f\n"
                 asm volatile("s_mov_b64 %[exec0], exec\n\t"
                              "s_mov_b32 s43, %[idx]\n\t"
+                             "s_mov_b32 %[bskip], %[idx]\n\t"
                              "s_cmp_lg_u32 %[bcnt], 0\n\t"                // inside a leaf block (the sink flushed): go on with it
                              "s_cbranch_scc1 6f\n"
                              "1:\n\t"
-                             "s_lshl_b32 %[off], s43, 5\n\t"                 // s43: the node to fetch, then its skip link
-                             "s_load_dwordx8 s[40:47], %[base], %[off]\n\t"
+                             "s_lshl_b32 %[t0], s43, 5\n\t"                // s43: the node to fetch, then its skip link
+                             "s_load_dwordx8 s[40:47], %[base], %[t0]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
                              COL_CMPX6("s40", "s41", "s42", "s44", "s45", "s46")
                              "s_cbranch_execnz 2f\n\t"                     // somebody overlaps
                              "s_mov_b64 exec, %[exec0]\n"
                              "8:\n\t"
-                             "s_cmp_lg_u32 s43, -1\n\t"                    // nobody (or the leaf / block is done): follow the skip link
-                             "s_cbranch_scc1 1b\n\t"
+                             "s_cmp_lg_u32 s43, -1\n\t"                    // nobody (or the leaf is done): follow the skip link
+                             "s_cbranch_scc1 1b\n"
+                             "9:\n\t"
                              "s_mov_b32 %[idx], -1\n\t"
-                             "s_mov_b64 %[hits], 0\n\t"
+                             "s_mov_b64 %[hits], 0\n\t"                    // (EXEC is full again on every path that gets here)
                              "s_branch 4f\n"
                              "2:\n\t"
-                             "s_cmp_ge_u32 %[off], %[leaf]\n\t"
+                             "s_cmp_ge_u32 %[t0], %[leaf]\n\t"
                              "s_cbranch_scc1 3f\n\t"
                              "s_mov_b64 exec, %[exec0]\n\t"
                              "s_bitcmp1_b32 s47, 31\n\t"                  // a leaf block?
-                             "s_cbranch_scc1 7f\n\t"
+                             "s_cbranch_scc1 30f\n\t"
                              "s_mov_b32 s43, s47\n\t"                      // an internal node: descend (down link) and go on
                              "s_branch 1b\n"
                              "3:\n\t"                                       // a leaf: stage (my id, its id) for the hit lanes
-                             "s_mov_b32 %[pid], s47\n\t"
-                             COL_STAGE("s47", "5f")
+                             "s_mov_b32 %[bskip], s43\n\t"
+                             COL_STAGE("s47", "39f")
                              "s_mov_b64 exec, %[exec0]\n\t"
                              "s_branch 8b\n"
-                             "7:\n\t"                                       // a leaf block: count and offset of its first leaf record
+                             "30:\n\t"                                      // a leaf block: count, offset of its first leaf record
+                             "s_mov_b32 %[bskip], s43\n\t"
                              "s_and_b32 %[bcnt], s47, 15\n\t"
                              "s_add_u32 %[bcnt], %[bcnt], 1\n\t"
                              "s_bfe_u32 %[boff], s47, 0x1b0004\n\t"        // bits 4..30: the first leaf
                              "s_lshl_b32 %[boff], %[boff], 5\n\t"
                              "s_add_u32 %[boff], %[boff], %[leaf]\n"
-                             "6:\n\t"
-                             "s_load_dwordx8 s[48:55], %[base], %[boff]\n"
-                             "9:\n\t"
-                             COL_CAND("s48", "s49", "s50", "s52", "s53", "s54", "s55", "s[56:63]", "11", "5f")
-                             COL_CAND("s56", "s57", "s58", "s60", "s61", "s62", "s63", "s[48:55]", "21", "5f")
+                             "6:\n\t"                                       // candidates 0, 1 -> s[40:55], candidate 2 -> s[56:63]
+                             "s_load_dwordx16 s[40:55], %[base], %[boff]\n\t"
+                             "s_cmp_lt_u32 %[bcnt], 3\n\t"
+                             "s_cbranch_scc1 31f\n\t"
+                             "s_add_u32 %[t0], %[boff], 64\n\t"
+                             "s_load_dwordx8 s[56:63], %[base], %[t0]\n"
+                             "31:\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             COL_CAND("0", "s40", "s41", "s42", "s44", "s45", "s46", "s47")
+                             COL_CAND("1", "s48", "s49", "s50", "s52", "s53", "s54", "s55")
+                             "s_cmp_lt_u32 %[bcnt], 4\n\t"                 // candidates 3, 4 while 2 is compared
+                             "s_cbranch_scc1 32f\n\t"
+                             "s_add_u32 %[t0], %[boff], 96\n\t"
+                             "s_load_dwordx16 s[40:55], %[base], %[t0]\n"
+                             "32:\n\t"
+                             COL_CAND("2", "s56", "s57", "s58", "s60", "s61", "s62", "s63")
+                             "s_sub_u32 %[bcnt], %[bcnt], 3\n\t"
+                             "s_add_u32 %[boff], %[boff], 96\n\t"
+                             "s_cmp_lt_u32 %[bcnt], 3\n\t"                 // (candidates 0, 1 of the next group are in flight already)
+                             "s_cbranch_scc1 31b\n\t"
+                             "s_add_u32 %[t0], %[boff], 64\n\t"
+                             "s_load_dwordx8 s[56:63], %[base], %[t0]\n\t"
+                             "s_branch 31b\n"
+                             "7:\n\t"                                       // the block is done: on along the marked node's skip link
+                             "s_mov_b32 %[bcnt], 0\n\t"
+                             "s_mov_b32 s43, %[bskip]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"                   // (a load for candidates beyond the count may be in flight)
+                             "s_cmp_lg_u32 s43, -1\n\t"
+                             "s_cbranch_scc1 1b\n\t"
                              "s_branch 9b\n"
+                             COL_CAND_FULL("0", "s47") COL_CAND_FULL("1", "s55") COL_CAND_FULL("2", "s63")
+                             "39:\n\t"
+                             "s_mov_b32 %[t0], s47\n"
                              "5:\n\t"                                       // the staging area is full: let the sink flush it
                              "s_mov_b64 %[hits], exec\n\t"
                              "s_mov_b64 exec, %[exec0]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n"                      // (a prefetched candidate may still be in flight)
+                             "s_mov_b32 %[idx], %[bskip]\n\t"             // where the walk goes on (behind the leaf / the block)
+                             "s_waitcnt lgkmcnt(0)\n"                      // (prefetched candidates may still be in flight)
                              "4:"
-                             : [idx] "+s"(idx), [cnt] "+s"(sink.count), [bcnt] "+s"(bcnt), [boff] "+s"(boff), [hits] "=s"(hits),
-                               [off] "=&s"(off), [t0] "=&s"(t0), [pid] "=&s"(pid), [v0] "=&v"(v0), [v1] "=&v"(v1),
-                               [exec0] "=&s"(exec0), "=&{s[40:47]}"(r)
-                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [capw] "s"((u32)CAPW), [buf] "s"(buf_lds),
+                             : [idx] "+s"(idx), [cnt] "+s"(sink.count), [bcnt] "+s"(bcnt), [boff] "+s"(boff), [hits] "=&s"(hits), [exec0] "=&s"(exec0),
+                               [t0] "=&s"(pid), [bskip] "=&s"(bskip), [v0] "=&v"(v0), [v1] "=&v"(v1)
+                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 32u), [buf] "s"(buf_lds),
                                [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
-                             : "vcc", "scc", "memory", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-                               "s59", "s60", "s61", "s62", "s63");
+                             : "vcc", "scc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+                               "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63");
+#undef COL_CAND_FULL
 #undef COL_CAND
 #undef COL_STAGE
 #undef COL_CMPX6
-                if (!hits) break;                                           // the chain ended (idx == END)
-                sink.emit(hits, qid, pid);                                  // the staging area was full: flush, then stage
-                idx = (u32)r[3];                                            // and on: the rest of the block (bcnt), then the skip link
-            }
+                if (!hits) break;                                           // the chain ended (idx == END, no block pending)
+                sink.emit(hits, qid, pid);                                  // the staging area was full: flush, then stage;
+            }                                                               // then on: the rest of the block (bcnt), the skip link (idx)
         } else if constexpr (sizeof(T) == 4 && WALK == 2 && !VEC) {
             typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
