@@ -110,6 +110,52 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         res[name + "_mean"] = sum(each) / len(each)
         res[name + "_p10_p90"] = (each[len(each) // 10], each[(9 * len(each)) // 10])
 
+    # The ceiling of the pass's ACCESS PATTERN on this box: the kernel itself -- same loads, same LDS staging, same stores
+    # at the same addresses -- with the ranking taken away (diagnostics mode 65536), run on the pass's tile-sorted image
+    # (which mode 2 writes).  `hist` still holds pass 0's scanned histogram.
+    pattern = None
+    try:
+        from collision_amd._lib import cdll
+        simg_k, simg_v = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+        cdll().col_debug_radix(2)
+        call.col_radix_scatter(cq.stream, kin.ptr, simg_k.ptr, vin.ptr, simg_v.ptr, n, 4, 4, 0, hist.ptr)
+        cq.finish()
+        cdll().col_debug_radix(0)
+        call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)      # the real pass
+        pk, pv = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+
+        def store_pattern():       # (mode 65536: the kernel itself on its tile-sorted image, ranking skipped)
+            call.col_radix_scatter(cq.stream, simg_k.ptr, pk.ptr, simg_v.ptr, pv.ptr, n, 4, 4, 0, hist.ptr)
+        cdll().col_debug_radix(65536)
+        store_pattern()
+        cq.finish()
+        cdll().col_debug_radix(0)
+        got_k, want_k = hip.read_buffer(cq, pk, np.uint32, n), hip.read_buffer(cq, kout, np.uint32, n)
+        got_v, want_v = hip.read_buffer(cq, pv, np.uint32, n), hip.read_buffer(cq, vout, np.uint32, n)
+        same = bool((got_k == want_k).all() and (got_v == want_v).all())
+        del got_k, want_k, got_v, want_v
+        def timed(mode, fn):
+            cdll().col_debug_radix(mode)
+            for _ in range(40):
+                fn()
+            cq.finish()
+            each = time_events_each(hip, cq, fn, SCATTER_TIMED)
+            cdll().col_debug_radix(0)
+            return each
+        # three interleaved series on the same box state: the ranking-free kernel on the sorted image; the SAME
+        # diagnostics instance doing the full production work (mode bit 20 is a no-op: the instance carries the
+        # diagnostic branches and is a few per cent slower than the production one); the production instance
+        each = timed(65536, store_pattern)
+        diag_full = timed(1 << 20, scatter)
+        again = timed(0, scatter)
+        pattern = {"launch_ms": each[len(each) // 2], "p10_p90": (each[len(each) // 10], each[(9 * len(each)) // 10]),
+                   "diag_instance_full_work_ms": diag_full[len(diag_full) // 2],
+                   "kernel_ms_right_after": again[len(again) // 2], "same_output_as_the_pass": same}
+        del simg_k, simg_v, pk, pv
+    except Exception as exc:                                    # (diagnostics leg: never lose the bench line over it)
+        pattern = {"error": repr(exc)}
+        cdll().col_debug_radix(0)
+
     def histo():
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
     for _ in range(10):
@@ -122,7 +168,7 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         "scatter_ms": scatter_ms, "scatter_ms_top_digit": res["pass3"], "hist_ms": hist_ms,
         "scatter_gbs": algo_bytes / scatter_ms / 1e6,
         "scatter_ms_cold": res["pass0_cold"], "scatter_ms_mean": res["pass0_mean"], "scatter_ms_p10_p90": res["pass0_p10_p90"],
-        "algo_bytes_per_launch": algo_bytes,
+        "algo_bytes_per_launch": algo_bytes, "pattern": pattern,
     }
 
 
@@ -535,6 +581,20 @@ def main():
                         "launches_timed": SCATTER_TIMED, "warmup_launches": SCATTER_WARMUP,
                         "launch_ms_first_20_after_idle": round(rb["scatter_ms_cold"], 4),
                         "traffic": None}
+            pat = rb.get("pattern")
+            if pat and "launch_ms" in pat:
+                # the memory side of the same pass with the ranking taken away: what the access pattern -- ~128-byte runs at
+                # 4-byte alignment -- allows on THIS box; the kernel is measured against it
+                roofline["pattern_ceiling"] = {
+                    "what": "the kernel on its tile-sorted image with the ranking skipped: same loads, LDS staging and stores (col_debug_radix 65536)",
+                    "launch_ms": round(pat["launch_ms"], 4), "launch_ms_p10_p90": [round(v, 4) for v in pat["p10_p90"]],
+                    "frac_of_hbm_peak": round(rb["algo_bytes_per_launch"] / pat["launch_ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                    "same_instance_with_ranking_ms": round(pat["diag_instance_full_work_ms"], 4),
+                    "ranking_costs": round(pat["diag_instance_full_work_ms"] / pat["launch_ms"] - 1.0, 4),
+                    "production_kernel_ms_right_after": round(pat["kernel_ms_right_after"], 4),
+                    "same_output_as_the_pass": pat["same_output_as_the_pass"]}
+            elif pat:
+                roofline["pattern_ceiling"] = pat
             if world == 1 and not args.no_pmc:
                 roofline["traffic"], roofline["traffic_detail"] = pmc_traffic()
                 roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of tools/radix_only.py in this "

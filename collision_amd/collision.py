@@ -63,9 +63,13 @@ class Collider:
         # Sort plan for inputs of up to 4 M spheres (include/collision_hip.h, col_collide_plan): the MSD sort
         # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
-        # then take the LSD sort, and the MSD one is tried again after PLAN_RETRY calls (doubling up to
-        # PLAN_RETRY_MAX while it keeps failing).  No host sync: the
-        # word is read when the next call is made.  sort_plan = "lsd" / "msd" pins the choice (a captured
+        # then take the LSD sort, and every LSD call reports how clustered its codes were (the largest group
+        # sharing the top six code bits = four MSD buckets): while that says a bucket could not fit, the MSD
+        # plan is not tried at all -- a clustered scene pays for ONE slow probe, not one every PLAN_RETRY
+        # calls; when it no longer says so, the MSD plan is tried again after PLAN_RETRY calls (doubling up to
+        # PLAN_RETRY_MAX while it keeps failing).  No host sync: the words are read when the next call is made
+        # (a kernel still in flight may write word 0 after the host cleared it: the worst case is one more LSD
+        # period).  sort_plan = "lsd" / "msd" pins the choice (a captured
         # hipGraph replays whichever plan the captured call chose: pin "lsd" for clustered scenes).
         self.sort_plan = "auto"
         self._plan_word = None
@@ -152,6 +156,7 @@ class Collider:
             call.col_host_alloc(C.byref(word), 64)
             self._plan_word = word.value
             C.c_uint32.from_address(self._plan_word).value = 0
+            C.c_uint32.from_address(self._plan_word + 4).value = 0
         if self.sort_plan == "msd":          # pinned: the kernel still reports an oversize bucket (self.oversize_bucket)
             return 1
         flag = C.c_uint32.from_address(self._plan_word)
@@ -165,8 +170,16 @@ class Collider:
         if self._lsd_calls_left:
             self._lsd_calls_left -= 1
             return 0
+        # the last LSD call's report (word 1): a group of four buckets above 4 x the capacity cannot fit
+        report = C.c_uint32.from_address(self._plan_word + 4).value
+        if report & 0x80000000 and (report & 0x7FFFFFFF) > 4 * self._msd_bucket_capacity():
+            return 0
         self._tried_msd = True
         return 1
+
+    def _msd_bucket_capacity(self):
+        """Pairs one workgroup of the MSD plan's LDS finish holds (csrc/radix.hip: k_bucket_sort<8> / <16>)."""
+        return 8192 if self.padded_size <= 1900000 else 16384
 
     @property
     def oversize_bucket(self):

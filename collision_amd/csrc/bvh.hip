@@ -947,6 +947,8 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
         if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;
+        // the LSD plan was taken where the MSD plan could apply: tell the caller how clustered the codes are (oversize[1])
+        if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_coarse_report(stream, sort_scratch, padded, oversize + 1))) return rc;
     } else {
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
         if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;

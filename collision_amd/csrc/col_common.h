@@ -50,6 +50,7 @@ extern "C" int col_morton_tile(void *stream, const void *coords, const void *rad
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 
+extern "C" int col_radix_coarse_report(void *stream, const void *scratch, uint64_t n, uint32_t *word);   // see radix.hip
 extern "C" int col_radix_tile_override_active(void);      // diagnostics: col_debug_radix_tile() is in force
 
 static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }

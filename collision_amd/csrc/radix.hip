@@ -266,8 +266,13 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     __syncthreads();
     STAMP(0)      // load + transpose
 
+    // (diagnostics, mode 65536: the input IS the pass's tile-sorted image (mode 2 wrote it) -- an element's slot is its
+    // own index, the digit counts come from the offsets table: no match-any, no counters.  Everything else -- loads,
+    // LDS staging, the stores and their addresses -- is the production code: the kernel's ceiling without its ranking.)
+    const bool norank = DIAG && (dbg & 65536);
     // rank inside (wave, digit): wave-private counters, program order keeps them consistent
     u32 pos[IT];
+    if (!norank) {
 #pragma unroll
     for (int k = 0; k < IT; k++) {
         const u32 d = digit_of(key[k], shift);
@@ -279,9 +284,26 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         if (below == 0) s_cnt[w][d] = prev + (u32)__popcll(peers);
         pos[k] = prev + below;
     }
+    }
     __syncthreads();
     STAMP(1)      // ranking
 
+    if (norank) {
+#pragma unroll
+        for (int k = 0; k < IT; k++) pos[k] = wbase + k * COL_WAVE;
+        u32 cnt = 0;
+        if (tid < RDIG) {
+            const uint64_t flat = (uint64_t)tid * nblocks + b;
+            cnt = (flat + 1 < (uint64_t)RDIG * nblocks ? offsets[flat + 1] : (u32)n) - my_offset;
+        }
+        u32 total;
+        const u32 dstart = block_excl_scan<NT>(cnt, s_ws, &total);
+        if (tid < RDIG) {
+            s_goff[tid] = my_offset - dstart;
+            for (int i = 0; i < NW; i++) s_cnt[i][tid] = 0;
+            if (DIAG) s_dstart[tid] = dstart;
+        }
+    } else
     // digit `tid` (threads 0..255): exclusive over waves, then exclusive over digits; fold both into s_cnt
     {
         u32 c[NW], tot = 0;
@@ -943,6 +965,20 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
                : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass * 8, offsets);
 }
 
+// After an LSD sort of 30-bit codes (col_radix_sort_ex on `scratch`): the largest group of codes sharing their top SIX
+// bits (the pass-3 digit; pads 0xFFFFFFFF are digit 255 and do not count), read off the scanned histogram the last pass
+// left at the start of `scratch`, published as 0x80000000 | max in a host-visible word.  Four MSD buckets make one such
+// group, so a group above 4 x the MSD finish's capacity means the MSD plan WOULD meet an oversize bucket: the caller
+// (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a probe.  One launch of one wave.
+__global__ __launch_bounds__(COL_WAVE) void k_coarse_report(const u32 *__restrict__ offsets, u32 nblocks, u32 n, u32 *word) {
+    const u32 c = threadIdx.x;                                                   // digits 0..63: the 6 top bits of a 30-bit code
+    u32 cnt = offsets[(uint64_t)(c + 1) * nblocks] - offsets[(uint64_t)c * nblocks];
+    (void)n;
+#pragma unroll
+    for (int o = COL_WAVE / 2; o > 0; o >>= 1) cnt = max(cnt, (u32)__shfl_xor((int)cnt, o, COL_WAVE));
+    if (c == 0) __hip_atomic_store(word, 0x80000000u | min(cnt, 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs up to
 // COL_MSD_MAX_N pairs.  The histogram of the bucket digit (bits 22..29, digit-major, one row entry per tile
 // of col_radix_tile(n) pairs) must already be at the start of `scratch` (col_morton_tile writes it).
@@ -971,6 +1007,14 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
         k_bucket_sort<8><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
     else
         k_bucket_sort<16><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+int col_radix_coarse_report(void *stream, const void *scratch, uint64_t n, uint32_t *word) {
+    if (!scratch || !word || n == 0 || n >= 0xFFFFFFFFull) return COL_EINVAL;
+    const u32 nb = tiles_of(n, 4, 4);
+    k_coarse_report<<<dim3(1), dim3(COL_WAVE), 0, col_stream(stream)>>>((const u32 *)scratch, nb, (u32)n, word);
     COL_LAUNCH_OK();
     return COL_OK;
 }

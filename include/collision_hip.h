@@ -224,9 +224,12 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
  *   COL_SORT_MSD  one global pass on the top 8 code bits, then every bucket finished inside one workgroup's
  *                 LDS -- 6 launches less.  Same outputs.  A bucket of more than 8192 pairs (16384 above 1.9 M
  *                 spheres; clustered scenes)
- *                 is still sorted correctly but slowly, and its size is stored to *oversize (memory the
- *                 device can write, e.g. from col_host_alloc; may be NULL): the caller should then go back to
- *                 COL_SORT_LSD.  collision_amd.collision.Collider does that on its own. */
+ *                 is still sorted correctly but slowly, and its size is stored to oversize[0] (TWO words of memory
+ *                 the device can write, e.g. from col_host_alloc; may be NULL): the caller should then go back
+ *                 to COL_SORT_LSD.  A call that takes COL_SORT_LSD where the MSD plan could apply stores
+ *                 0x80000000 | g to oversize[1], g = the largest group of codes that share their top six bits
+ *                 (four MSD buckets): g above 4 x the bucket capacity means the MSD plan would certainly meet
+ *                 an oversize bucket.  collision_amd.collision.Collider follows both on its own. */
 /* The MSD plan's sort on its own: (u32 code, u32 id) pairs, codes 30-bit or the 0xFFFFFFFF pad, n up to
  * 4 000 000.  The digit-major histogram of the bucket digit (bits 22..29) per col_radix_tile(n)-code tile --
  * what the fused Morton kernel leaves -- must be at the start of `scratch` (col_radix_scratch_bytes(n, 4, 4)). */

@@ -313,6 +313,42 @@ def test_back_to_back_calls_on_a_clustered_scene(oracle, hip_env):
     assert int(hip.read_buffer(cq, outs[1][0], np.uint32, 1)[0]) == ref["count"]
 
 
+def test_a_clustered_scene_pays_for_one_msd_probe_only(oracle, hip_env):
+    """Every LSD call reports how clustered its codes were (the largest group sharing the top six code bits = four MSD
+    buckets); while that exceeds 4 x the bucket capacity the MSD plan is not tried again: 300 calls on a clustered
+    scene take it exactly once.  When the scene stops being clustered the MSD plan comes back."""
+    from collision_amd import hip
+    from tests.util import upload
+    ctx, cq = hip_env
+    n = 150000
+    coords, radii = clustered_scene(n, 0.003, 0.0003, "float32")
+    collider = Collider(ctx, n, 8, 64, np.dtype("float32"))
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=1 << 24)
+    cb, rb = upload(ctx, pad4(coords)), upload(ctx, radii)
+    nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, ref["count"] * 8)
+    plans = []
+    choose = collider._choose_sort_plan
+    collider._choose_sort_plan = lambda: plans.append(choose()) or plans[-1]
+    for _ in range(300):
+        collider.get_collisions(cq, cb, rb, nb, pb, ref["count"])
+        cq.finish()
+    assert plans[0] == 1 and sum(plans) == 1, plans[:80]
+    assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == ref["count"]
+    assert_same_pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2)), ref["pairs"])
+    # the same collider on a uniform scene: the next LSD call reports small groups, the MSD plan is taken again
+    ucoords, uradii = uniform_scene(n, 0.004, "float32")
+    uref = oracle.collide(oracle.pad4(ucoords), uradii, padded=collider.padded_size, capacity=1 << 24)
+    ub, urb, upb = upload(ctx, pad4(ucoords)), upload(ctx, uradii), hip.Buffer(ctx, max(uref["count"], 1) * 8)
+    del plans[:]
+    for _ in range(collider.PLAN_RETRY_MAX // 16):
+        collider.get_collisions(cq, ub, urb, nb, upb, uref["count"])
+        cq.finish()
+        if plans[-1] == 1:
+            break
+    assert plans[-1] == 1 and len(plans) <= 3, plans
+    assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == uref["count"]
+
+
 @pytest.mark.parametrize("k", [0.0, 1.5, 3.0, 1e30])
 @pytest.mark.parametrize("scene", ["clustered", "identical", "uniform_dense", "tiny_capacity"])
 def test_leaf_blocks_do_not_change_the_result(hip_env, oracle, k, scene):
