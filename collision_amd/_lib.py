@@ -102,8 +102,9 @@ _PROTOS = {
                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]),
     "col_pack_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
                               C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "col_ghost_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
+                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_debug_traverse": (C.c_int, [C.c_int]),

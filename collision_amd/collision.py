@@ -63,8 +63,8 @@ class Collider:
         # Sort plan for inputs of up to 4 M spheres (include/collision_hip.h, col_collide_plan): the MSD sort
         # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
-        # then take the LSD sort, and every LSD call reports how clustered its codes were (the largest group
-        # sharing the top six code bits = four MSD buckets): while that says a bucket could not fit, the MSD
+        # then take the LSD sort, and every LSD call reports the largest MSD bucket of its codes (read off the
+        # sorted codes: one small launch): while that says a bucket could not fit, the MSD
         # plan is not tried at all -- a clustered scene pays for ONE slow probe, not one every PLAN_RETRY
         # calls; when it no longer says so, the MSD plan is tried again after PLAN_RETRY calls (doubling up to
         # PLAN_RETRY_MAX while it keeps failing).  No host sync: the words are read when the next call is made
@@ -170,9 +170,9 @@ class Collider:
         if self._lsd_calls_left:
             self._lsd_calls_left -= 1
             return 0
-        # the last LSD call's report (word 1): a group of four buckets above 4 x the capacity cannot fit
+        # the last LSD call's report (word 1): its largest MSD bucket; above the capacity the plan would fail again
         report = C.c_uint32.from_address(self._plan_word + 4).value
-        if report & 0x80000000 and (report & 0x7FFFFFFF) > 4 * self._msd_bucket_capacity():
+        if report & 0x80000000 and (report & 0x7FFFFFFF) > self._msd_bucket_capacity():
             return 0
         self._tried_msd = True
         return 1

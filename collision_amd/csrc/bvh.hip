@@ -247,11 +247,16 @@ struct PairSink {
     u32 *counter;
     u32 capacity;
     u32 lane;
+    const u32 *gids;   // ghost queries: the second id of a staged pair is a local sphere index -> gids[index]; else NULL
 
     __device__ __forceinline__ void copy_out(u32 base, u32 cnt) {
         for (u32 i = lane; i < cnt; i += 64) {
             const u32 k = base + i;
-            if (k < capacity) *reinterpret_cast<uint2 *>(pairs + 2ull * k) = buf[i];
+            if (k < capacity) {
+                uint2 pr = buf[i];
+                if (gids) pr.y = gids[pr.y];
+                *reinterpret_cast<uint2 *>(pairs + 2ull * k) = pr;
+            }
         }
     }
     __device__ __forceinline__ void flush() {          // wave-level, count > 0
@@ -308,10 +313,19 @@ template <typename T, bool MAX> __device__ __forceinline__ T wave_min_max(T v) {
 // no counters.  VEC: record loads as vector loads at a uniform address (ablation).
 // WALK: 0 = the generic phase-2 loop; 1 = the asm walk with the in-loop leaf-block test (needs 32-bit record offsets);
 // 2 = the asm walk without it (marked nodes are entered through their leaf chain): the A/B reference of col_debug_traverse(128)
-template <typename T, bool STATS, bool VEC, int WALK>
+// GHOST: the queries are not the tree's own leaves but GHOST spheres (multi-GPU halo, csrc/multi.hip): transport records
+// (x, y, z, r, gid) addressed through `order` -- record numbers sorted by the ghosts' Morton codes, so that the 64
+// ghosts of a packet are neighbours in space -- `*count` of them; a packet has no phase 1 and its walk starts at the
+// ROOT (no position pruning: every local leaf is a candidate); pairs come out as (ghost gid, local gid).
+struct GhostArgs { const u32 *rec; const u32 *order; const u32 *count; const u32 *gids; };
+struct NoGhost {};
+template <bool G> struct GhostSel { typedef NoGhost T; };
+template <> struct GhostSel<true> { typedef GhostArgs T; };
+
+template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false>
 __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
-                                                  int mode) {
+                                                  int mode, typename GhostSel<GHOST>::T ghost = {}) {
     typedef typename BTypes<T>::V4 V4;
     typedef typename BTypes<T>::Bits Bits;
     __shared__ uint2 s_buf[TW][CAPW];
@@ -322,8 +336,12 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const u32 leaf_start = n - 1;
     const bool marks = n <= COL_LEAF_BLOCK_MAX_N;      // internal nodes over <= 16 leaves carry leaf-block marks
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
-    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
-    const u32 npackets = (n + 63) / 64;
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr};
+    u32 npackets = (n + 63) / 64;
+    if constexpr (GHOST) {
+        sink.gids = ghost.gids;
+        npackets = (*ghost.count + 63u) / 64u;
+    }
     u64 trips = 0, descents = 0, leaf_tests = 0, leaf_hits = 0, win[4] = {0, 0, 0, 0};
 
     // XCD-aware order: blockIdx % 8 is the XCD, each with its own L2.  Neighbouring packets walk nearly
@@ -342,19 +360,35 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         const u32 q0 = packet * 64, q = q0 + lane;
         T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;      // empty box: overlaps nothing
         u32 qid = 0, qskip = END;
-        if (q < n) {
+        if constexpr (GHOST) {
+            if (q < *ghost.count) {
+                constexpr int RW = 4 * (int)(sizeof(T) / 4) + 1;        // words per transport record (multi.hip)
+                const u32 *o = ghost.rec + (u64)RW * ghost.order[q];
+                T c[4];
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c[k] = __uint_as_float(o[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c[k] = __longlong_as_double((long long)(((u64)o[2 * k + 1] << 32) | o[2 * k]));
+                }
+                lx = c[0] - c[3]; ly = c[1] - c[3]; lz = c[2] - c[3];    // same arithmetic as leafBounds, collision.cl:139-140
+                hx = c[0] + c[3]; hy = c[1] + c[3]; hz = c[2] + c[3];
+                qid = o[RW - 1];
+            }
+        } else if (q < n) {
             const V4 a = rows[2ull * (leaf_start + q)], b = rows[2ull * (leaf_start + q) + 1];
             lx = a.x; ly = a.y; lz = a.z; hx = b.x; hy = b.y; hz = b.z;
             qskip = (u32) * reinterpret_cast<const Bits *>(&a.w);
             qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
         }
-        const int last = (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
+        const int last = GHOST ? 0 : (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
         // phase 1: pairs inside the packet.  Exact float tests cost ~30 wave-instructions per pair
         // and almost all of them fail, so pairs are first screened with boxes quantised to 8 bits
         // per axis inside the packet's union box (lo rounded down, hi rounded up: a real overlap
         // always survives).  The three axes sit in 10-bit fields of one word, and "a >= b in every
         // field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
-        if (!(mode & 1)) {
+        if (!GHOST && !(mode & 1)) {
             // the packet's union box: six wave reductions on the DPP network (6 steps + one v_readlane each,
             // no LDS) instead of six xor-shuffle butterflies through ds_bpermute (36 LDS round trips)
             T ul[3], uh[3];
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         // addc; arrays below 4 GB), the six compares narrow EXEC (v_cmpx: lanes that fail drop out, the survivors
         // are the hits) instead of producing six masks to AND, and runs of misses -- more than half of all steps --
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
-        u32 idx = (u32)__builtin_amdgcn_readlane((int)qskip, last);
+        u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
         if (mode & 2) idx = END;
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             const char *rows_b = reinterpret_cast<const char *>(rows);
@@ -743,7 +777,7 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
     const u32 leaf_start = n - 1;
     const bool marks = n <= COL_LEAF_BLOCK_MAX_N;
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
-    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane};
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr};
     const u32 npackets = (n + 63) / 64;
     for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += gridDim.x * TW) {
         const u32 q = packet * 64 + lane;
@@ -816,7 +850,36 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     return COL_OK;
 }
 
+template <typename T>
+int launch_ghost(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds, uint32_t n,
+                 const GhostArgs &ga, uint32_t max_ghosts) {
+    const u32 npackets = (max_ghosts + 63) / 64;
+    u32 blocks = (u32)col_ceil_div(npackets, TW);
+    if (blocks > 512) blocks = 512;
+    if (blocks == 0) return COL_OK;
+    dim3 g(blocks), t(TT);
+    hipStream_t s = col_stream(stream);
+    const T *bd = (const T *)bounds;
+    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
+    if (off32) k_traverse<T, false, false, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
+    else k_traverse<T, false, false, 0, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
+
 }  // namespace
+
+// ghost spheres as packets of 64 Morton-sorted queries against the tree in `bounds` (see GhostArgs); internal, called
+// by col_traverse_ghost_slots (multi.hip).  `count` (device) = the number of sorted ghosts, at most max_ghosts.
+extern "C" int col_traverse_ghost_packets(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
+                                          uint32_t n, int coord_bytes, const uint32_t *rec, const uint32_t *order,
+                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids) {
+    if (n == 0 || max_ghosts == 0) return COL_OK;
+    const GhostArgs ga = {rec, order, count, local_gids};
+    if (coord_bytes == 4) return launch_ghost<float>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts);
+    if (coord_bytes == 8) return launch_ghost<double>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts);
+    return COL_EINVAL;
+}
 
 extern "C" {
 
@@ -948,7 +1011,7 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;
         // the LSD plan was taken where the MSD plan could apply: tell the caller how clustered the codes are (oversize[1])
-        if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_coarse_report(stream, sort_scratch, padded, oversize + 1))) return rc;
+        if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_bucket_report(stream, codes1, padded, oversize + 1))) return rc;
     } else {
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
         if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;

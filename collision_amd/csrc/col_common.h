@@ -50,7 +50,12 @@ extern "C" int col_morton_tile(void *stream, const void *coords, const void *rad
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 
-extern "C" int col_radix_coarse_report(void *stream, const void *scratch, uint64_t n, uint32_t *word);   // see radix.hip
+extern "C" int col_traverse_ghost_packets(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
+                                          uint32_t n, int coord_bytes, const uint32_t *rec, const uint32_t *order,
+                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids);   // bvh.hip
+extern "C" int col_radix_sort_low_passes(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
+                                         uint32_t *vals_out, uint64_t n, void *scratch, int passes);      // radix.hip
+extern "C" int col_radix_bucket_report(void *stream, const uint32_t *sorted_codes, uint64_t n, uint32_t *word);   // see radix.hip
 extern "C" int col_radix_tile_override_active(void);      // diagnostics: col_debug_radix_tile() is in force
 
 static inline hipStream_t col_stream(void *s) { return (hipStream_t)s; }

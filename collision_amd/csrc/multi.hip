@@ -206,6 +206,39 @@ __global__ __launch_bounds__(GW * 64) void k_ghost(const typename MT<T>::V4 *__r
     }
 }
 
+// Ghost queries as PACKETS (the default; k_ghost above is the lane-per-query walk kept for A/B and as the fallback
+// without scratch): k_ghost_codes gives every received record a coarse Morton key (the top 15 bits of its 30-bit code
+// under the local tree's root box -- cells of ~1/32 of the scene's extent per axis, ~60 leaves each at 2 M spheres) and
+// its record number; two 8-bit sort passes order the record numbers by key; bvh.hip's packet walk then takes 64
+// neighbouring ghosts per wave from the root (wave-uniform record per step, leaf blocks) -- the walk the local
+// queries use, which DESIGN 4.6 measured 1.3-1.8x faster than the lane-per-query one even before leaf blocks.
+// Entries beyond a slot's length get key 0xFFFF (sorted last; real keys are below 0x8000) and are never read:
+// the walk runs over flags[1] ghosts, the count this kernel accumulates.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ghost_codes(const u32 *__restrict__ rec, u32 slot, const typename MT<T>::V4 *__restrict__ rows,
+                                                      u32 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ flags) {
+    typedef typename MT<T>::V4 V4;
+    const u32 s = blockIdx.y, g = blockIdx.x * 256 + threadIdx.x;
+    const u32 *base = rec + (u64)MT<T>::RW * s * (slot + 1);
+    const u32 len = base[0], cnt = min(len, slot);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && len) {
+        atomicMax(&flags[0], len);
+        atomicAdd(&flags[1], cnt);
+    }
+    if (g >= slot) return;
+    const u64 e = (u64)s * slot + g;
+    u32 key = 0xFFFFu, val = 0xFFFFFFFFu;
+    if (g < cnt) {
+        const V4 lo = rows[0], hi = rows[1];                  // the root's box (node 0)
+        u32 gid;
+        const V4 c = rec_load<T>(base + (u64)MT<T>::RW * (1 + g), &gid);
+        key = morton30<T>(c.x, c.y, c.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) >> 15;
+        val = s * (slot + 1) + 1 + g;                         // record number in `rec`
+    }
+    keys[e] = key;
+    vals[e] = val;
+}
+
 // pairs[first .. min(*count, capacity)) hold local indices: replace by gids[index]
 __global__ __launch_bounds__(256) void k_translate(u32 *__restrict__ pairs, const u32 *__restrict__ count, u32 first,
                                                     u32 capacity, const u32 *__restrict__ gids) {
@@ -808,13 +841,34 @@ int col_pack_slots(void *stream, const void *rows, const uint32_t *gids, const u
     return COL_OK;
 }
 
+size_t col_ghost_scratch_bytes(uint32_t n_slots, uint32_t slot_records) {
+    const uint64_t e = (uint64_t)n_slots * slot_records;
+    return 4 * (((size_t)e * 4 + 255) & ~(size_t)255) + col_radix_scratch_bytes(e, 4, 4) + 256;
+}
+
+// scratch: col_ghost_scratch_bytes(n_slots, slot_records) bytes, or NULL for the lane-per-query walk (k_ghost).
 int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
                              uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
-                             uint32_t *flags, int coord_bytes) {
+                             uint32_t *flags, int coord_bytes, void *scratch) {
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     if (n_slots == 0 || slot_records == 0 || n == 0) return COL_OK;
     if ((capacity > 0 && !pairs) || !flags) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
+    const uint64_t e = (uint64_t)n_slots * slot_records;
+    if (scratch && local_gids && e < 0xFFFFFFFFull && (uint64_t)n_slots * (slot_records + 1) < 0xFFFFFFFFull) {
+        const size_t seg = ((size_t)e * 4 + 255) & ~(size_t)255;
+        char *p = (char *)scratch;
+        u32 *keys0 = (u32 *)p, *vals0 = (u32 *)(p + seg), *keys1 = (u32 *)(p + 2 * seg), *vals1 = (u32 *)(p + 3 * seg);
+        void *sort_scratch = p + 4 * seg;
+        dim3 grid(blocks_for(slot_records), n_slots);
+        COL_BY_COORD((k_ghost_codes<float><<<grid, dim3(256), 0, s>>>((const u32 *)rec, slot_records, (const float4 *)bounds, keys0, vals0, flags)),
+                     (k_ghost_codes<double><<<grid, dim3(256), 0, s>>>((const u32 *)rec, slot_records, (const double4 *)bounds, keys0, vals0, flags)));
+        COL_LAUNCH_OK();
+        int rc = col_radix_sort_low_passes(stream, keys0, keys1, vals0, vals1, e, sort_scratch, 2);
+        if (rc) return rc;
+        return col_traverse_ghost_packets(stream, pairs, counter, capacity, bounds, n, coord_bytes, (const u32 *)rec, vals1,
+                                          flags + 1, (uint32_t)e, local_gids);
+    }
     dim3 grid((unsigned)col_ceil_div(slot_records, GW * 64), n_slots), block(GW * 64);
     COL_BY_COORD((k_ghost<float><<<grid, block, 0, s>>>((const float4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags)),
                  (k_ghost<double><<<grid, block, 0, s>>>((const double4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags)));

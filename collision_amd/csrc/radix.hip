@@ -29,6 +29,7 @@ namespace {
 
 constexpr int RT = 256;             // threads per block
 constexpr int RDIG = 256;           // 8-bit digits
+constexpr int BS_SHIFT_REPORT = 22; // == BS_SHIFT below: the MSD plan's bucket digit is bits 22..29 of a code
 // Tile classes (threads x items per thread), template parameters of the kernels:
 //   SMALL 256 x 4  = 1024 pairs  below SMALL_N pairs: a pass is bound by the latency of one block, and
 //                                more, shorter blocks finish sooner (the 1 M-sphere path);
@@ -965,18 +966,39 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
                : launch_scatter<uint64_t>(col_stream(stream), keys, keys_out, vals, vals_out, n, val_bytes, pass * 8, offsets);
 }
 
-// After an LSD sort of 30-bit codes (col_radix_sort_ex on `scratch`): the largest group of codes sharing their top SIX
-// bits (the pass-3 digit; pads 0xFFFFFFFF are digit 255 and do not count), read off the scanned histogram the last pass
-// left at the start of `scratch`, published as 0x80000000 | max in a host-visible word.  Four MSD buckets make one such
-// group, so a group above 4 x the MSD finish's capacity means the MSD plan WOULD meet an oversize bucket: the caller
-// (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a probe.  One launch of one wave.
-__global__ __launch_bounds__(COL_WAVE) void k_coarse_report(const u32 *__restrict__ offsets, u32 nblocks, u32 n, u32 *word) {
-    const u32 c = threadIdx.x;                                                   // digits 0..63: the 6 top bits of a 30-bit code
-    u32 cnt = offsets[(uint64_t)(c + 1) * nblocks] - offsets[(uint64_t)c * nblocks];
-    (void)n;
+// After an LSD sort of 30-bit codes: the size of the largest MSD bucket (codes sharing bits 22..29) read off the SORTED
+// codes -- thread d finds where bucket d starts by a binary search -- published as 0x80000000 | max in a host-visible
+// word.  A bucket above the MSD finish's capacity means the MSD plan WOULD take its slow path: the caller
+// (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a second probe.  One small launch.
+__global__ __launch_bounds__(RDIG) void k_bucket_report(const u32 *__restrict__ sorted, u32 n, u32 *word) {
+    __shared__ u32 s_start[RDIG + 1];
+    const u32 d = threadIdx.x;
+    const u32 want = d << BS_SHIFT_REPORT;
+    u32 lo = 0, hi = n;                        // first position whose code is >= want
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (sorted[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    s_start[d] = lo;
+    if (d == 0) {                              // end of bucket 255: the first pad (0xFFFFFFFF) or n
+        u32 l2 = 0, h2 = n;
+        while (l2 < h2) {
+            const u32 mid = l2 + ((h2 - l2) >> 1);
+            if (sorted[mid] < (1u << 30)) l2 = mid + 1; else h2 = mid;
+        }
+        s_start[RDIG] = l2;
+    }
+    __syncthreads();
+    u32 cnt = s_start[d + 1] - s_start[d];
 #pragma unroll
     for (int o = COL_WAVE / 2; o > 0; o >>= 1) cnt = max(cnt, (u32)__shfl_xor((int)cnt, o, COL_WAVE));
-    if (c == 0) __hip_atomic_store(word, 0x80000000u | min(cnt, 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if ((d & 63u) == 0) s_start[d >> 6] = cnt;
+    __syncthreads();
+    if (d == 0) {
+        const u32 m = max(max(s_start[0], s_start[1]), max(s_start[2], s_start[3]));
+        __hip_atomic_store(word, 0x80000000u | min(m, 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs up to
@@ -1011,10 +1033,18 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
     return COL_OK;
 }
 
-int col_radix_coarse_report(void *stream, const void *scratch, uint64_t n, uint32_t *word) {
-    if (!scratch || !word || n == 0 || n >= 0xFFFFFFFFull) return COL_EINVAL;
-    const u32 nb = tiles_of(n, 4, 4);
-    k_coarse_report<<<dim3(1), dim3(COL_WAVE), 0, col_stream(stream)>>>((const u32 *)scratch, nb, (u32)n, word);
+static int sort_passes(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
+                       uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0, int passes);
+// (u32 key, u32 value) pairs whose keys are below 2^(8 * passes): only that many digit passes (internal)
+int col_radix_sort_low_passes(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
+                              uint32_t *vals_out, uint64_t n, void *scratch, int passes) {
+    if (passes < 1 || passes > 4) return COL_EINVAL;
+    return sort_passes(stream, keys, keys_out, vals, vals_out, n, 4, 4, scratch, 0, 0, passes);
+}
+
+int col_radix_bucket_report(void *stream, const uint32_t *sorted_codes, uint64_t n, uint32_t *word) {
+    if (!sorted_codes || !word || n == 0 || n >= 0xFFFFFFFFull) return COL_EINVAL;
+    k_bucket_report<<<dim3(1), dim3(RDIG), 0, col_stream(stream)>>>(sorted_codes, (u32)n, word);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -227,9 +227,9 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
  *                 is still sorted correctly but slowly, and its size is stored to oversize[0] (TWO words of memory
  *                 the device can write, e.g. from col_host_alloc; may be NULL): the caller should then go back
  *                 to COL_SORT_LSD.  A call that takes COL_SORT_LSD where the MSD plan could apply stores
- *                 0x80000000 | g to oversize[1], g = the largest group of codes that share their top six bits
- *                 (four MSD buckets): g above 4 x the bucket capacity means the MSD plan would certainly meet
- *                 an oversize bucket.  collision_amd.collision.Collider follows both on its own. */
+ *                 0x80000000 | g to oversize[1], g = the largest MSD bucket of ITS codes (read off the sorted
+ *                 codes): g above the bucket capacity means the MSD plan would have met an oversize bucket.
+ *                 collision_amd.collision.Collider follows both on its own. */
 /* The MSD plan's sort on its own: (u32 code, u32 id) pairs, codes 30-bit or the 0xFFFFFFFF pad, n up to
  * 4 000 000.  The digit-major histogram of the bucket digit (bits 22..29) per col_radix_tile(n)-code tile --
  * what the fused Morton kernel leaves -- must be at the start of `scratch` (col_radix_scratch_bytes(n, 4, 4)). */
@@ -319,10 +319,15 @@ int col_pack_slots(void *stream, const void *rows, const uint32_t *gids, const u
                    uint32_t slot_records, int coord_bytes);
 /* ghost spheres (n_slots received slots) as queries against the local tree (bounds with links); emits
  * (ghost gid, local_gids[hit]); counter is NOT reset (it continues the local pair list);
- * flags[0] = max(flags[0], longest header length), flags[1] += ghosts queried (2 x uint32, zeroed by the caller) */
+ * flags[0] = max(flags[0], longest header length), flags[1] += ghosts queried (2 x uint32, zeroed by the caller).
+ * scratch (col_ghost_scratch_bytes(n_slots, slot_records) bytes): the ghosts are ordered by a coarse Morton key (one
+ * launch + two 8-bit sort passes) and walk the tree as PACKETS of 64 neighbours, like the local queries (4 + 6
+ * launches); scratch == NULL: one launch, every lane walks its own ghost from the root (slower beyond a few
+ * thousand ghosts). */
+size_t col_ghost_scratch_bytes(uint32_t n_slots, uint32_t slot_records);
 int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
                              uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter,
-                             uint32_t capacity, uint32_t *flags, int coord_bytes);
+                             uint32_t capacity, uint32_t *flags, int coord_bytes, void *scratch);
 /* pairs[first .. min(*count, capacity)) : index -> gids[index] */
 int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first,
                         uint32_t capacity, const uint32_t *gids);

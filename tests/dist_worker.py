@@ -127,7 +127,7 @@ class OracleEngine(_protocol_ops()):
             self.halo_send[base, 0] = len(idx)
             self.pack5(rows, gids, idx, 0, min(len(idx), slot), self.halo_send, base + 1)
 
-    def ghost_queries(self, n_in, slot, owned_gids):
+    def ghost_queries(self, n_in, slot, owned_gids, expected=None):
         for k in range(n_in):
             base = k * (slot + 1)
             length = int(self.halo_recv[base, 0])

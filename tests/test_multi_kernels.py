@@ -263,11 +263,17 @@ def test_halo_select_pack_and_ghost_queries(hip_env, oracle, dt, n, n_peers, slo
     nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, 8)
     col.get_collisions(cq, upload(ctx, local), upload(ctx, np.ascontiguousarray(local[:, 3])), nb, None, 0)
     cap = 1 << 22
-    pairs, counter, flags = hip.Buffer(ctx, cap * 8), upload(ctx, np.zeros(1, np.uint32)), upload(ctx, np.zeros(4, np.uint32))
-    call.col_traverse_ghost_slots(cq.stream, send.ptr, n_peers, slot, col._bounds_buf.ptr, m, upload(ctx, lg).ptr,
-                                  pairs.ptr, counter.ptr, cap, flags.ptr, cb)
-    count = int(download(cq, counter, np.uint32, 1)[0])
-    got = download(cq, pairs, np.uint32, (min(count, cap), 2))
+    results = []
+    for packets in (True, False):          # the packet walk (Morton-ordered ghosts, 64 per wave) and the lane-per-ghost walk
+        pairs, counter, flags = hip.Buffer(ctx, cap * 8), upload(ctx, np.zeros(1, np.uint32)), upload(ctx, np.zeros(4, np.uint32))
+        scratch = hip.Buffer(ctx, call.col_ghost_scratch_bytes(n_peers, slot)) if packets else None
+        call.col_traverse_ghost_slots(cq.stream, send.ptr, n_peers, slot, col._bounds_buf.ptr, m, upload(ctx, lg).ptr,
+                                      pairs.ptr, counter.ptr, cap, flags.ptr, cb, scratch.ptr if packets else None)
+        count = int(download(cq, counter, np.uint32, 1)[0])
+        results.append((count, download(cq, pairs, np.uint32, (min(count, cap), 2)), download(cq, flags, np.uint32, 4)))
+    (count, got, f), (count_lane, got_lane, f_lane) = results
+    assert count == count_lane and sorted(map(tuple, got.tolist())) == sorted(map(tuple, got_lane.tolist()))
+    np.testing.assert_array_equal(f, f_lane)
     llo, lhi = local[:, :3] - local[:, 3:4], local[:, :3] + local[:, 3:4]
     expect = []
     n_ghosts = 0
@@ -279,5 +285,4 @@ def test_halo_select_pack_and_ghost_queries(hip_env, oracle, dt, n, n_peers, slo
             expect += [(int(gids[s]), int(lg[j])) for j in np.nonzero(hit)[0]]
     assert count == len(expect) <= cap
     assert sorted(map(tuple, got.tolist())) == sorted(expect)
-    f = download(cq, flags, np.uint32, 4)
     assert f[0] == max([len(w) for w in want] + [0]) and f[1] == n_ghosts

@@ -314,9 +314,9 @@ def test_back_to_back_calls_on_a_clustered_scene(oracle, hip_env):
 
 
 def test_a_clustered_scene_pays_for_one_msd_probe_only(oracle, hip_env):
-    """Every LSD call reports how clustered its codes were (the largest group sharing the top six code bits = four MSD
-    buckets); while that exceeds 4 x the bucket capacity the MSD plan is not tried again: 300 calls on a clustered
-    scene take it exactly once.  When the scene stops being clustered the MSD plan comes back."""
+    """Every LSD call reports the largest MSD bucket of its codes (read off the sorted codes); while that exceeds the
+    bucket capacity the MSD plan is not tried again: 300 calls on a clustered scene take it exactly once.  When the
+    scene stops being clustered the MSD plan comes back."""
     from collision_amd import hip
     from tests.util import upload
     ctx, cq = hip_env
