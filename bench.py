@@ -34,6 +34,7 @@ SORT_KEYS = 1 << 26         # BASELINE config 5
 SORT_WARMUP = 20            # whole sorts before the timed ones
 SCATTER_WARMUP, SCATTER_TIMED = 100, 200    # k_scatter launches: untimed, then the timed region (one event per launch)
 N_PER_RANK_MULTI = 2000000  # BASELINE config 4: 16 M spheres over 8 GPUs
+COMPULSORY_BYTES_PER_SPHERE = 340   # bounds + Morton + 4 sort passes + leaves + Karras + refit, f32 / u32
 
 
 def uniform_scene(n, seed=4):
@@ -218,8 +219,12 @@ def single_gpu_leg(hip, ctx, cq, n, reps=20):
         run()
     cq.finish()
     ms = time_events(hip, cq, run, reps)
+    # ~340 compulsory bytes per sphere for everything before the traversal (the traversal's own bytes are
+    # data-dependent and NOT counted: this understates the path's traffic and so its fraction of the HBM peak)
+    gbs = COMPULSORY_BYTES_PER_SPHERE * n / ms / 1e6
     return {"spheres": n, "ms_per_step": round(ms, 4), "m_spheres_per_s": round(n / ms / 1e3, 1),
-            "pairs": int(hip.read_buffer(cq, nb, np.uint32, 1)[0])}
+            "pairs": int(hip.read_buffer(cq, nb, np.uint32, 1)[0]),
+            "compulsory_gb_per_s": round(gbs, 1), "compulsory_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
 
 def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
@@ -615,6 +620,8 @@ def main():
                 extra["config3_clustered"] = config3_leg(hip, ctx, cq)
                 extra["radix_sort"]["gkeys_per_s_other_distributions"] = config5_variants(hip, ctx, cq)
                 extra["config4_per_rank_size_on_one_gpu"] = single_gpu_leg(hip, ctx, cq, N_PER_RANK_MULTI)
+                # config 4's whole scene on ONE GPU: the regime where the path runs out of HBM, not out of the caches
+                extra["config4_whole_scene_on_one_gpu"] = single_gpu_leg(hip, ctx, cq, 8 * N_PER_RANK_MULTI, reps=5)
                 extra["reference_benchmark_shapes_ms"] = reference_benchmark_shapes(hip, ctx, cq)
         cpu = None
         if not args.no_cpu and world == 1:

@@ -73,7 +73,7 @@ struct PeerList { int q[8]; int n; };
 // spheres (1.1-1.5 ms with the hash partition, where every sphere is selected).  So a block takes SEL_ROWS rows per
 // thread, remembers the outcome of its box tests in registers (a bit per row and peer), and reserves its share of
 // each list with ONE atomic per block and peer after a block scan of the hit counts.
-constexpr int SEL_ROWS = 8;
+constexpr int SEL_ROWS = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *__restrict__ rows, u32 n,
                                                        const typename MT<T>::V4 *__restrict__ boxes, PeerList pl, u32 stride,

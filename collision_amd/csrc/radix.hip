@@ -98,8 +98,10 @@ __device__ __forceinline__ u64 match8(u32 d) {
 }
 
 // ---- histogram: blocks handle `g` consecutive tiles and write g-entry rows per digit ----
+// (amdgpu_num_sgpr: above 80 SGPRs a wave's allocation -- with the 16 the trap handler reserves on this platform -- no
+// longer lets 8 waves share a SIMD; unconstrained, hipcc takes 102 here for the unrolled ballots)
 template <typename K, int TILE>
-__global__ __launch_bounds__(RT) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
+__global__ __launch_bounds__(RT) __attribute__((amdgpu_num_sgpr(80))) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
                                              int shift, u32 *__restrict__ hist) {
     constexpr int IT = TILE / RT;
     __shared__ u32 h[HG * RDIG];
@@ -150,6 +152,8 @@ template <int SCOPE, typename X> __device__ __forceinline__ void st_scope(X *p, 
 }
 
 // ---- scatter ----
+template <bool NARROW> struct CntType { typedef u32 T; };
+template <> struct CntType<true> { typedef uint16_t T; };
 template <typename K, int VB, int IT, int NT, bool DIAG>
 __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
@@ -163,7 +167,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     typedef typename Val<(VB > 0 ? VB : 4)>::T V;
     __shared__ __attribute__((aligned(16))) K s_keys[TILE];
     __shared__ __attribute__((aligned(16))) V s_vals[V_LDS ? TILE : 1];
-    __shared__ u32 s_cnt[NW][RDIG];
+    // (wave, digit) counters: at most 64 * IT items per wave and TILE per block, so 16 bits do when a block has 16 waves --
+    // with 32-bit counters the 1024-thread instance would not fit two blocks into a CU's LDS
+    typedef typename CntType<(NT > 512)>::T CNT;
+    __shared__ CNT s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
     __shared__ u32 s_ws[NW];
     __shared__ u32 s_dstart[DIAG ? RDIG : 1];        // (diagnostics, mode 8192)
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     // this tile's global offset of digit `tid`: one scattered 4-byte load per thread, issued now so that
     // its latency hides under the loads and the ranking instead of sitting between two barriers
     const u32 my_offset = tid < RDIG ? offsets[(uint64_t)tid * nblocks + b] : 0u;
-    for (u32 i = tid; i < NW * RDIG; i += NT) (&s_cnt[0][0])[i] = 0;
+    for (u32 i = tid; i < NW * RDIG; i += NT) (&s_cnt[0][0])[i] = (CNT)0;
 
     const u32 wbase = w * (COL_WAVE * IT) + lane;
     K key[IT];
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         // every lane of the group reads the counter (same address: a broadcast), then the group's
         // lowest lane bumps it; LDS operations of one wave execute in order, so no lane sees the bump
         const u32 prev = s_cnt[w][d];
-        if (below == 0) s_cnt[w][d] = prev + (u32)__popcll(peers);
+        if (below == 0) s_cnt[w][d] = (CNT)(prev + (u32)__popcll(peers));
         pos[k] = prev + below;
     }
     }
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
         if (tid < RDIG) {
             u32 run = dstart;
 #pragma unroll
-            for (int i = 0; i < NW; i++) { s_cnt[i][tid] = run; run += c[i]; }
+            for (int i = 0; i < NW; i++) { s_cnt[i][tid] = (CNT)run; run += c[i]; }
             // global position of tile-sorted slot i with digit d is s_goff[d] + i
             s_goff[tid] = my_offset - dstart;
             if (DIAG) s_dstart[tid] = dstart;
@@ -743,6 +750,7 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 // EVERY caller in the process and are not synchronised -- set them from one thread, with no sort in flight.
 int g_radix_dbg = 0;
 int g_radix_tile_override = 0;      // 0 = automatic, else 1024 / 4096 / 8192 / 16384
+int g_radix_wide_block = 0;         // the 8192-pair tile with 1024 threads x 8 items (experiment, col_debug_radix_tile(8193))
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool huge_ok(int key_bytes, int val_bytes) { return key_bytes == 4 && val_bytes == 0; }
 inline u32 tile_auto(uint64_t n, int key_bytes, int val_bytes) {
@@ -854,6 +862,9 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
             }
             return COL_OK;
         }
+        // the 8192-pair tile as 1024 threads x 8 items (32 waves per CU instead of 16, same LDS): col_debug_radix_tile(8193)
+        if (g_radix_wide_block && (vb == 0 || vb == 4 || vb == 8))
+            return launch_scatter_it<K, IT_BIG / 2, NT_BIG * 2>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
         return launch_scatter_it<K, IT_BIG, NT_BIG>(s, keys, keys_out, vals, vals_out, n, vb, shift, offsets);
     }
     return COL_EINVAL;
@@ -917,6 +928,7 @@ extern "C" {
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
 int col_debug_radix_tile(int tile) {
+    if (tile == 8193 || tile == 8194) { g_radix_wide_block = tile == 8193; return COL_OK; }      // (8194: back to 512 x 16)
     if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE) return COL_EINVAL;
     g_radix_tile_override = tile;
     return COL_OK;
