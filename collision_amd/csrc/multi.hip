@@ -72,47 +72,57 @@ struct PeerList { int q[8]; int n; };
 // and with most waves holding a hit or two the first version of this kernel spent 0.3-0.4 ms there at 2 M owned
 // spheres (1.1-1.5 ms with the hash partition, where every sphere is selected).  So a block takes SEL_ROWS rows per
 // thread, remembers the outcome of its box tests in registers (a bit per row and peer), and reserves its share of
-// each list with ONE atomic per block and peer after a block scan of the hit counts.
-constexpr int SEL_ROWS = 4;
+// each list with ONE atomic per block and peer after a block scan of the hit counts (at most 512 blocks, each with
+// up to 32 rows per thread: ~2 k atomics on four addresses at 2 M rows; 4 rows per thread -- 7.8 k -- still took 55 us).
+constexpr int SEL_ROWS = 32;      // at most: rows per thread, one mask bit each
 template <typename T>
 __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *__restrict__ rows, u32 n,
                                                        const typename MT<T>::V4 *__restrict__ boxes, PeerList pl, u32 stride,
-                                                       u32 *__restrict__ lists, u32 *__restrict__ counts) {
+                                                       u32 *__restrict__ lists, u32 *__restrict__ counts, u32 per_thread) {
     typedef typename MT<T>::V4 V4;
     __shared__ u32 s_warp[4];
     __shared__ u32 s_base;
     const u32 tid = threadIdx.x;
-    const u32 base = blockIdx.x * (256u * SEL_ROWS);
-    V4 c[SEL_ROWS];
+    const u32 base = blockIdx.x * (256u * per_thread);      // this block's rows: [base, base + 256 * per_thread)
+    u32 mask[8];
 #pragma unroll
-    for (int j = 0; j < SEL_ROWS; j++) {
+    for (int k = 0; k < 8; k++) mask[k] = 0;
+    // the rows are only looked at, never kept: what a thread remembers is one bit per row and peer, and what goes
+    // into a list is the row's index
+    for (u32 j = 0; j < per_thread; j++) {
         const u32 i = base + j * 256u + tid;
-        if (i < n) c[j] = rows[i];
-        else { c[j].x = c[j].y = c[j].z = (T)NAN; c[j].w = (T)0; }      // (NaN: overlaps nothing)
-    }
-    for (int k = 0; k < pl.n; k++) {
-        const V4 *region = boxes + 2 * COL_REGION_BOXES * pl.q[k];      // wave-uniform
-        u32 mask = 0;
+        if (i >= n) break;
+        const V4 c = rows[i];
+        const T lx = c.x - c.w, ly = c.y - c.w, lz = c.z - c.w, hx = c.x + c.w, hy = c.y + c.w, hz = c.z + c.w;
 #pragma unroll
-        for (int o = 0; o < COL_REGION_BOXES; o++) {
-            const V4 lo = region[2 * o], hi = region[2 * o + 1];
+        for (int k = 0; k < 8; k++) {
+            if (k >= pl.n) break;
+            const V4 *region = boxes + 2 * COL_REGION_BOXES * pl.q[k];      // wave-uniform
+            bool hit = false;
 #pragma unroll
-            for (int j = 0; j < SEL_ROWS; j++) {
-                const bool hit = c[j].x + c[j].w > lo.x && c[j].x - c[j].w < hi.x && c[j].y + c[j].w > lo.y &&
-                                 c[j].y - c[j].w < hi.y && c[j].z + c[j].w > lo.z && c[j].z - c[j].w < hi.z;   // strict, as collision.cl:164-166
-                mask |= (u32)hit << j;
+            for (int o = 0; o < COL_REGION_BOXES; o++) {
+                const V4 lo = region[2 * o], hi = region[2 * o + 1];
+                hit |= hx > lo.x && lx < hi.x && hy > lo.y && ly < hi.y && hz > lo.z && lz < hi.z;   // strict, as collision.cl:164-166
             }
+            mask[k] |= (u32)hit << j;
         }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= pl.n) break;
         u32 total;
-        const u32 before = block_excl_scan<256>((u32)__popc(mask), s_warp, &total);
+        const u32 before = block_excl_scan<256>((u32)__popc(mask[k]), s_warp, &total);
         if (total == 0) continue;                                        // (block-uniform)
-        if (tid == 0) s_base = atomicAdd(&counts[k], total);
+        if (tid == 0) s_base = atomicAdd(&counts[k], total);             // ONE reservation per block and peer
         __syncthreads();
         u32 pos = s_base + before;
         __syncthreads();                                                 // (s_base is reused by the next peer)
-#pragma unroll
-        for (int j = 0; j < SEL_ROWS; j++)
-            if ((mask >> j) & 1u) lists[(uint64_t)k * stride + pos++] = base + j * 256u + tid;
+        u32 m = mask[k];
+        while (m) {
+            const u32 j = (u32)__builtin_ctz(m);
+            m &= m - 1;
+            lists[(uint64_t)k * stride + pos++] = base + j * 256u + tid;
+        }
     }
 }
 
@@ -358,8 +368,37 @@ __global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>:
     for (int o = 0; o < COL_REGION_BOXES; o++)
 #pragma unroll
         for (int k = 0; k < 7; k++) v[o][k] = k < 3 ? (T)INFINITY : -(T)INFINITY;
-    T mnx = 0, mny = 0, mnz = 0, mxx = 1, mxy = 1, mxz = 1;
-    if (range8) { mnx = range8[0]; mny = range8[1]; mnz = range8[2]; mxx = range8[4]; mxy = range8[5]; mxz = range8[6]; }
+    // The octant of a row = the top bit of each axis' 10-bit coordinate, exactly as morton30 quantises it (the octant
+    // must be the code's own top bits: with a geometric 'side of the middle' test the few spheres between 0.5 and
+    // 512/1023 of the range straddle the owner's Morton ranges, their octant boxes become slabs across the scene, and
+    // the N = 2 rehearsal sends 100 834 ghosts instead of 7 261).  quantize() is monotone in its argument, so per
+    // axis there is ONE threshold: the smallest coordinate whose quantised value reaches 512.  Three threads find
+    // it by bisection over the ordered bit patterns (32 / 64 evaluations); the 2 M rows then cost three compares each
+    // instead of three correctly rounded divisions (this kernel took 91 us beside the local pipeline, now ~15).
+    __shared__ T s_thr[3];
+    if (tid < 3) {
+        typedef typename MT<T>::Bits Bits;
+        T thr = (T)INFINITY;
+        if (range8) {
+            const T mn = range8[tid], mx = range8[4 + tid];
+            constexpr Bits SIGN = (Bits)1 << (8 * sizeof(T) - 1);
+            auto from_ord = [](Bits o) -> T { const Bits b = (o & SIGN) ? (o ^ SIGN) : ~o; return *reinterpret_cast<const T *>(&b); };
+            // ordered patterns: 0 .. SIGN-1 the negative floats (most negative first), SIGN .. the non-negative ones;
+            // search [ord(-inf), ord(+inf)] for the first value x with quantize(x) >= 512
+            const T ninf = -(T)INFINITY, pinf = (T)INFINITY;
+            Bits lo = ~*reinterpret_cast<const Bits *>(&ninf), hi = *reinterpret_cast<const Bits *>(&pinf) ^ SIGN;
+            if (quantize<T>(pinf, mn, mx) >= 512u) {
+                while (lo < hi) {
+                    const Bits mid = lo + ((hi - lo) >> 1);
+                    if (quantize<T>(from_ord(mid), mn, mx) >= 512u) hi = mid; else lo = mid + 1;
+                }
+                thr = from_ord(lo);
+            } else thr = (T)NAN;                    // (a degenerate range: no coordinate reaches the upper half)
+        }
+        s_thr[tid] = thr;
+    }
+    __syncthreads();
+    const T tx = s_thr[0], ty = s_thr[1], tz = s_thr[2];
     const u32 stride = gridDim.x * REGION_NT;
     for (u32 i0 = blockIdx.x * REGION_NT + tid; i0 < n; i0 += RU * stride) {
         V4 cc[RU];
@@ -368,10 +407,7 @@ __global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>:
 #pragma unroll
         for (int u = 0; u < RU; u++) {
             const V4 c = cc[u];
-            // (the octant must be the code's own top bits: with a geometric 'side of the middle' test the few spheres
-            // between 0.5 and 512/1023 of the range straddle the owner's Morton ranges, their octant boxes become
-            // slabs across the scene, and the N = 2 rehearsal sends 100 834 ghosts instead of 7 261)
-            const u32 oct = range8 ? morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz) >> 27 : 0u;
+            const u32 oct = range8 ? ((u32)(c.x >= tx) << 2) | ((u32)(c.y >= ty) << 1) | (u32)(c.z >= tz) : 0u;
             const T e[3] = {c.x, c.y, c.z};
 #pragma unroll
             for (int o = 0; o < COL_REGION_BOXES; o++)
@@ -530,8 +566,9 @@ __global__ __launch_bounds__(1024) void k_splitters(const typename MT<T>::V4 *__
 // One block per tile of the radix scatter that groups the spheres by owner: Morton code of every row under the
 // global range, its owner (the number of splitters <= code), and the tile's owner histogram in the digit-major
 // layout of radix.hip (hist[owner * nblocks + tile]) -- the code itself is never stored.
+constexpr int OWN_NT = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void k_owners(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
+__global__ __launch_bounds__(OWN_NT) void k_owners(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
                                                  const u32 *__restrict__ splitters, u32 world, u32 tile, u32 nblocks,
                                                  u32 *__restrict__ dest, u32 *__restrict__ hist) {
     typedef typename MT<T>::V4 V4;
@@ -539,30 +576,44 @@ __global__ __launch_bounds__(256) void k_owners(const typename MT<T>::V4 *__rest
     __shared__ u32 h[256];
     const u32 tid = threadIdx.x, lane = lane_id();
     if (tid + 1 < world) sp[tid] = splitters[tid];
-    h[tid] = 0;
+    if (tid < 256) h[tid] = 0;
     const T mnx = range8[0], mny = range8[1], mnz = range8[2], mxx = range8[4], mxy = range8[5], mxz = range8[6];
     __syncthreads();
     const u64 base = (u64)blockIdx.x * tile;
-    for (u32 o = tid; o < tile; o += 256) {
-        const u64 i = base + o;
-        u32 q = 0xFFFFFFFFu;
-        if (i < n) {
-            const V4 c = rows[i];
-            const u32 code = morton30<T>(c.x, c.y, c.z, mnx, mny, mnz, mxx, mxy, mxz);
-            u32 lo = 0, hi = world - 1;              // first index with sp[idx] > code
-            while (lo < hi) {
-                const u32 mid = (lo + hi) >> 1;
-                if (sp[mid] <= code) lo = mid + 1; else hi = mid;
-            }
-            q = lo;
-            dest[i] = q;
+    // 1024 threads per tile (a 4096-row tile at 256 threads left two waves per SIMD on a 2 M-row input: 28 us for 40 MB)
+    // and four rows in flight per thread: the kernel is bound by the latency of its loads, not by their bytes
+    for (u32 o0 = tid; o0 < tile; o0 += 4 * OWN_NT) {
+        V4 c[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 o = o0 + u * OWN_NT;
+            const u64 i = base + o;
+            ok[u] = o < tile && i < n;
+            if (ok[u]) c[u] = rows[i];
         }
-        if (world <= 16) {                          // few owners: one ballot per owner instead of 64 atomics on 8 words
-            for (u32 d = 0; d < world; d++) {
-                const u64 m = __ballot(q == d);
-                if (m && lane == 0) atomicAdd(&h[d], (u32)__popcll(m));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 i = base + o0 + u * OWN_NT;
+            u32 q = 0xFFFFFFFFu;
+            if (ok[u]) {
+                const u32 code = morton30<T>(c[u].x, c[u].y, c[u].z, mnx, mny, mnz, mxx, mxy, mxz);
+                u32 lo = 0, hi = world - 1;              // first index with sp[idx] > code
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (sp[mid] <= code) lo = mid + 1; else hi = mid;
+                }
+                q = lo;
+                dest[i] = q;
             }
-        } else if (i < n) atomicAdd(&h[q], 1u);
+            if (o0 + u * OWN_NT - tid >= tile) continue;      // (block-uniform: no row of this group exists)
+            if (world <= 16) {                          // few owners: one ballot per owner instead of 64 atomics on 8 words
+                for (u32 d = 0; d < world; d++) {
+                    const u64 m = __ballot(q == d);
+                    if (m && lane == 0) atomicAdd(&h[d], (u32)__popcll(m));
+                }
+            } else if (ok[u]) atomicAdd(&h[q], 1u);
+        }
     }
     __syncthreads();
     if (tid < world) hist[(u64)tid * nblocks + blockIdx.x] = h[tid];
@@ -590,53 +641,104 @@ __global__ __launch_bounds__(1024) void k_owner_offsets(u32 *__restrict__ hist, 
     if (threadIdx.x < world) counts[threadIdx.x] = s_start[threadIdx.x + 1] - s_start[threadIdx.x];
 }
 
-// After the stable grouping (position i holds sphere perm[i] of owner owners[i]): the spheres this rank keeps go
-// straight to the front of its owned arrays; the others into the slot of their owner -- a header record whose
-// first word is the full length of the list, then min(length, slot) transport records.  What does NOT fit into a
-// slot STAYS WITH THIS RANK: it is appended to the owned arrays behind the kept rows (owner order).  Which rank owns
-// a sphere is a matter of load balance and halo size only -- the halo selection works on what a rank really owns --
-// so a slot that is too small costs locality for one step and never a sphere; the header (and flags[2], longest
-// list seen) tells the host to grow the slots for the steps that follow.
-template <typename T>
-__global__ __launch_bounds__(256) void k_partition_pack(const typename MT<T>::V4 *__restrict__ rows, const u32 *__restrict__ gids,
-                                                         const u32 *__restrict__ perm, const u32 *__restrict__ owners,
-                                                         const u32 *__restrict__ counts, u32 n, u32 world, u32 rank, u32 slot,
-                                                         u32 capacity, u32 *__restrict__ send, typename MT<T>::V4 *__restrict__ own_rows,
-                                                         u32 *__restrict__ own_gids, T *__restrict__ own_radii,
-                                                         u32 *__restrict__ flags) {
+// Stable grouping by owner and packing in ONE pass: the spheres this rank keeps go straight to the front of its owned
+// arrays; the others into the slot of their owner -- a header record whose first word is the full length of the list,
+// then min(length, slot) transport records.  What does NOT fit into a slot STAYS WITH THIS RANK: it is appended to the
+// owned arrays behind the kept rows (owner order).  Which rank owns a sphere is a matter of load balance and halo size
+// only -- the halo selection works on what a rank really owns -- so a slot that is too small costs locality for one
+// step and never a sphere; the header (and flags[2], longest list seen) tells the host to grow the slots.
+// A block takes the tile of rows whose owner counts k_owners wrote into column `tile` of the scanned owner histogram,
+// so row i of owner q lands at position hist[q][tile] - hist[q][0] + (its rank among the tile's rows of owner q) of
+// q's list.  (Rounds 1-2 sorted (owner, index) pairs with a radix scatter and gathered the rows through the
+// permutation: 16 random bytes per row pull a whole line, 50 of the 120 us this step took at 2 M rows.)
+// A wave owns a contiguous piece of the tile (16 waves per 4096-row tile: a block of 256 threads left the GPU two waves
+// per SIMD at 2 M rows): it counts its rows per owner (one ballot per owner and 64 rows), the block adds up the waves
+// before it, then the wave places every row.
+template <typename T, int CH, int NW>      // NW waves per tile, CH = 64-row chunks per wave: tile = 64 * CH * NW
+__global__ __launch_bounds__(NW * 64) void k_partition_scatter(const typename MT<T>::V4 *__restrict__ rows, const u32 *__restrict__ gids,
+                                                            const u32 *__restrict__ dest, const u32 *__restrict__ hist,
+                                                            const u32 *__restrict__ counts, u32 n, u32 world, u32 rank, u32 slot,
+                                                            u32 capacity, u32 nblocks, u32 *__restrict__ send,
+                                                            typename MT<T>::V4 *__restrict__ own_rows, u32 *__restrict__ own_gids,
+                                                            T *__restrict__ own_radii, u32 *__restrict__ flags) {
     constexpr int RW = MT<T>::RW;
-    __shared__ u32 s_warp[4];
-    __shared__ u32 s_start[256], s_stay[256];
-    const u32 tid = threadIdx.x;
-    const u32 cnt = tid < world ? counts[tid] : 0u;
-    u32 total;
-    s_start[tid] = block_excl_scan<256>(cnt, s_warp, &total);
-    // rows that stay here: all of this rank's own list, and the part of every other list beyond the slot
-    const u32 stay = tid == rank ? cnt : (cnt > slot ? cnt - slot : 0u);
-    s_stay[tid] = block_excl_scan<256>(stay, s_warp, &total);
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < world && tid != rank) {
+    __shared__ u32 s_wcnt[NW][16];
+    __shared__ u32 s_stay[16];
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid / COL_WAVE;
+    const u32 b = blockIdx.x;
+    const u64 wave_base = ((u64)b * NW + w) * (CH * COL_WAVE);      // a wave owns a contiguous piece of the tile
+    // the owners of this wave's rows, all loads in flight together (a loop that loads as it goes is bound by latency)
+    u32 d[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const u64 i = wave_base + c * COL_WAVE + lane;
+        d[c] = i < n ? dest[i] : 0xFFFFFFFFu;
+    }
+    // where the rows that stay here go: this rank's own list first, then the overflow of the other lists in owner order
+    if (tid < 16) {
+        u32 before = 0;
+        for (u32 q = 0; q < tid && q < world; q++) {
+            const u32 c = counts[q];
+            before += q == rank ? c : (c > slot ? c - slot : 0u);
+        }
+        s_stay[tid] = before;
+    }
+    if (b == 0 && tid < world && tid != rank) {
+        const u32 cnt = counts[tid];
         u32 *hdr = send + (u64)RW * (tid < rank ? tid : tid - 1) * (slot + 1);
         for (int k = 0; k < RW; k++) hdr[k] = k == 0 ? cnt : 0u;
         if (cnt) atomicMax(&flags[2], cnt);
     }
-    const u32 i = blockIdx.x * 256 + tid;
-    if (i >= n) return;
-    const u32 q = owners[i], pos = i - s_start[q], src = perm[i];
-    const typename MT<T>::V4 c = rows[src];
-    const u32 gid = gids[src];
-    if (q != rank && pos < slot) {
-        rec_store<T>(send + (u64)RW * ((u64)(q < rank ? q : q - 1) * (slot + 1) + 1 + pos), c, gid);
-        return;
+    // phase 1: lane q counts this wave's rows of owner q
+    u32 cnt = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+        for (u32 q = 0; q < world; q++) {
+            const u64 m = __ballot(d[c] == q);
+            if (lane == q) cnt += (u32)__popcll(m);
+        }
+    if (lane < 16) s_wcnt[w][lane] = cnt;
+    __syncthreads();
+    // lane q: position in q's list of this wave's first row of owner q
+    u32 run = 0;
+    if (lane < world) {
+        run = hist[(u64)lane * nblocks + b] - hist[(u64)lane * nblocks];
+        for (u32 ww = 0; ww < w; ww++) run += s_wcnt[ww][lane];
     }
-    // kept rows first (this rank's own list), then the overflow of the other lists in owner order
     const u32 kept = counts[rank];
-    const u32 before = s_stay[q] - (q > rank ? kept : 0u);      // overflow rows of owners below q
-    const u64 dst = q == rank ? (u64)pos : (u64)kept + before + (pos - slot);
-    if (dst >= capacity) return;                                 // (the unpack reports m > capacity)
-    own_rows[dst] = c;
-    own_gids[dst] = gid;
-    own_radii[dst] = c.w;
+    // phase 2: every row's position in its owner's list (registers only), then the rows themselves
+    u32 pos[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        u64 mine = 0;
+        u32 add = 0;
+        for (u32 q = 0; q < world; q++) {
+            const u64 m = __ballot(d[c] == q);
+            if (d[c] == q) mine = m;
+            if (lane == q) add = (u32)__popcll(m);
+        }
+        const u32 base = (u32)__shfl((int)run, d[c] < world ? (int)d[c] : 0, COL_WAVE);
+        run += add;
+        pos[c] = base + mbcnt(mine);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const u64 i = wave_base + c * COL_WAVE + lane;
+        const u32 q = d[c];
+        if (q >= world) continue;                                   // (beyond n)
+        const typename MT<T>::V4 r = rows[i];
+        const u32 gid = gids[i];
+        if (q != rank && pos[c] < slot) {
+            rec_store<T>(send + (u64)RW * ((u64)(q < rank ? q : q - 1) * (slot + 1) + 1 + pos[c]), r, gid);
+            continue;
+        }
+        const u32 before = s_stay[q] - (q > rank ? kept : 0u);
+        const u64 dst = q == rank ? (u64)pos[c] : (u64)kept + before + (pos[c] - slot);
+        if (dst >= capacity) continue;
+        own_rows[dst] = r;
+        own_gids[dst] = gid;
+        own_radii[dst] = r.w;
+    }
 }
 
 // Received slots (blockIdx.y = slot of the k-th other rank, in rank order) -> the owned arrays, behind the
@@ -753,31 +855,32 @@ int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint3
     }
     const u32 tile = (u32)col_radix_tile(n, 4, 4);
     const u32 nb = (u32)col_ceil_div(n, tile);
-    COL_BY_COORD((k_owners<float><<<dim3(nb), dim3(256), 0, s>>>((const float4 *)rows, n, (const float *)range8, splitters, world, tile, nb, dest, hist)),
-                 (k_owners<double><<<dim3(nb), dim3(256), 0, s>>>((const double4 *)rows, n, (const double *)range8, splitters, world, tile, nb, dest, hist)));
+    COL_BY_COORD((k_owners<float><<<dim3(nb), dim3(OWN_NT), 0, s>>>((const float4 *)rows, n, (const float *)range8, splitters, world, tile, nb, dest, hist)),
+                 (k_owners<double><<<dim3(nb), dim3(OWN_NT), 0, s>>>((const double4 *)rows, n, (const double *)range8, splitters, world, tile, nb, dest, hist)));
     COL_LAUNCH_OK();
     k_owner_offsets<<<dim3(1), dim3(1024), 0, s>>>(hist, nb, world, owner_counts);
     COL_LAUNCH_OK();
     return COL_OK;
 }
 
-// iota: 0, 1, 2, ... (n words); owners_sorted / perm: n words each.  send: (world - 1) slots of (slot + 1)
-// transport records, in rank order without this rank; own_*: `capacity` rows (kept rows, then what did not fit
-// into the slots).  flags[2] = max(flags[2], longest list).
+// send: (world - 1) slots of (slot + 1) transport records, in rank order without this rank; own_*: `capacity` rows
+// (kept rows, then what did not fit into the slots).  flags[2] = max(flags[2], longest list).  world <= 16 (as
+// col_partition_plan); dest / hist / owner_counts as col_partition_plan left them.
 int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
-                        const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world, uint32_t rank,
-                        uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows, uint32_t *own_gids,
+                        const uint32_t *hist, const uint32_t *owner_counts, uint32_t world, uint32_t rank,
+                        uint32_t slot, void *send, void *own_rows, uint32_t *own_gids,
                         void *own_radii, uint32_t capacity, uint32_t *flags, int coord_bytes) {
-    if (world == 0 || world > 256 || rank >= world || slot == 0 || !flags) return COL_EINVAL;
+    if (world == 0 || world > 16 || rank >= world || slot == 0 || !flags) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
-    if (n) {
-        int rc = col_radix_scatter(stream, dest, owners_sorted, iota, perm, n, 4, 4, 0, hist);
-        if (rc) return rc;
-    }
-    const unsigned g = n ? blocks_for(n) : 1u;          // (an empty rank still writes its slot headers)
-    COL_BY_COORD((k_partition_pack<float><<<dim3(g), dim3(256), 0, s>>>((const float4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, capacity, (u32 *)send, (float4 *)own_rows, own_gids, (float *)own_radii, flags)),
-                 (k_partition_pack<double><<<dim3(g), dim3(256), 0, s>>>((const double4 *)rows, gids, perm, owners_sorted, owner_counts, n, world, rank, slot, capacity, (u32 *)send, (double4 *)own_rows, own_gids, (double *)own_radii, flags)));
+    const u32 tile = n ? (u32)col_radix_tile(n, 4, 4) : 1024u;
+    const u32 nb = n ? (u32)col_ceil_div(n, tile) : 1u;          // (an empty rank still writes its slot headers)
+#define COL_PSCATTER(T, V, CH, NW) k_partition_scatter<T, CH, NW><<<dim3(nb), dim3(NW * 64), 0, s>>>((const V *)rows, gids, dest, hist, owner_counts, n, world, rank, slot, capacity, nb, (u32 *)send, (V *)own_rows, own_gids, (T *)own_radii, flags)
+    if (tile == 1024) { COL_BY_COORD(COL_PSCATTER(float, float4, 4, 4), COL_PSCATTER(double, double4, 4, 4)); }
+    else if (tile == 4096) { COL_BY_COORD(COL_PSCATTER(float, float4, 4, 16), COL_PSCATTER(double, double4, 4, 16)); }
+    else if (tile == 8192) { COL_BY_COORD(COL_PSCATTER(float, float4, 8, 16), COL_PSCATTER(double, double4, 8, 16)); }
+    else return COL_EINVAL;
+#undef COL_PSCATTER
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -819,8 +922,13 @@ int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const v
     pl.n = n_peers;
     for (int k = 0; k < 8; k++) pl.q[k] = k < n_peers ? peers[k] : -1;
     hipStream_t s = col_stream(stream);
-    COL_BY_COORD((k_select_multi<float><<<dim3((unsigned)col_ceil_div(n, 256 * SEL_ROWS)), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts)),
-                 (k_select_multi<double><<<dim3((unsigned)col_ceil_div(n, 256 * SEL_ROWS)), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts)));
+    // about 512 blocks; a thread takes at most SEL_ROWS rows (one mask bit each), so more blocks beyond 4 Mi rows
+    u32 per_thread = (u32)col_ceil_div(n, 512ull * 256);
+    if (per_thread < 1) per_thread = 1;
+    if (per_thread > (u32)SEL_ROWS) per_thread = SEL_ROWS;
+    const unsigned sel_blocks = (unsigned)col_ceil_div(n, 256ull * per_thread);
+    COL_BY_COORD((k_select_multi<float><<<dim3(sel_blocks), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts, per_thread)),
+                 (k_select_multi<double><<<dim3(sel_blocks), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts, per_thread)));
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -8,7 +8,7 @@ New work -- the reference is single-device.  Spheres arri
    Morton codes mean the same thing on every rank; the codes of the gathered samples give the splitters.
 2. **Spatial repartition** (``partition="morton"``, default): R-1 splitters = quantiles of the sample codes
    (balanced for clustered scenes too); owner of every sphere and the per-tile owner histogram (one launch,
-   the codes are never stored), scanned; one radix scatter groups the spheres by owner; one launch packs:
+   the codes are never stored), scanned; ONE launch groups and packs the spheres in a single pass over the rows:
    what the rank keeps goes STRAIGHT into its owned arrays (it never travels), the rest into one fixed-size
    SLOT per other rank -- a header record with the list's length, then transport records ``(x, y, z, r, id)``
    (5 words for f32 coordinates, 9 for f64).  ONE fixed-size all-to-all moves the slots: no count exchange;
@@ -320,8 +320,7 @@ class HipEngine(ProtocolOps):
 
         self._recs = recs
         self.rows_in, self.gids_in = rows(capacity), ints(capacity)
-        self.dest, self.owners_sorted, self.perm = ints(capacity), ints(capacity), ints(capacity)
-        self.iota = torch.arange(capacity, dtype=i32, device=dev)
+        self.dest = ints(capacity)
         nb_max = -(-capacity // call.col_radix_tile(1, 4, 4))            # the small tile bounds the block count
         self.hist = ints(256 * nb_max)
         self.owned_rows, self.owned_gids = rows(capacity), ints(capacity)
@@ -357,7 +356,7 @@ class HipEngine(ProtocolOps):
         self.n_owned = 0
         # pointers of the persistent buffers (the per-step C calls then convert nothing but a few integers)
         self._p = {k: getattr(self, k).data_ptr() for k in
-                   ("rows_in", "gids_in", "dest", "owners_sorted", "perm", "iota", "hist", "owned_rows", "owned_gids",
+                   ("rows_in", "gids_in", "dest", "hist", "owned_rows", "owned_gids",
                     "radii", "sel_lists", "sel_counts", "pairs", "counter", "flags", "owned2", "payload", "grange8",
                     "boxes", "split", "owner_counts", "_range_scratch", "_range_scratch_side", "_bounds_partials")}
 
@@ -421,10 +420,9 @@ class HipEngine(ProtocolOps):
 
     def partition_group(self, rows, gids, n, world, rank, slot):
         p = self._p
-        call.col_partition_group(self.cq.stream, rows.data_ptr(), gids.data_ptr(), n, p["dest"], p["iota"], p["hist"],
-                                 p["owner_counts"], world, rank, slot, p["owners_sorted"], p["perm"],
-                                 self.part_send.data_ptr(), p["owned_rows"], p["owned_gids"], p["radii"], self.capacity,
-                                 p["flags"], self.cb)
+        call.col_partition_group(self.cq.stream, rows.data_ptr(), gids.data_ptr(), n, p["dest"], p["hist"],
+                                 p["owner_counts"], world, rank, slot, self.part_send.data_ptr(), p["owned_rows"],
+                                 p["owned_gids"], p["radii"], self.capacity, p["flags"], self.cb)
 
     def partition_unpack(self, world, rank, slot):
         p = self._p

@@ -271,21 +271,22 @@ int col_partition_sample(void *stream, const void *rows, uint32_t n, uint32_t sa
 /* col_partition_plan (3 launches): gathered = [world][samples + 2] rows (every rank's payload; at most 16384 rows).
  * range8 = the global scene range; splitters = the world - 1 quantiles of the gathered rows' Morton codes;
  * dest[i] = owner of row i (number of splitters <= its code); hist (256 * ceil(n / col_radix_tile(n, 4, 4)) words)
- * = the scanned owner histogram col_partition_group needs; owner_counts[q] = rows of owner q. */
+ * = the scanned owner histogram col_partition_group needs; owner_counts[q] = rows of owner q.  An empty rank
+ * (n == 0): hist is not touched. */
 int col_partition_plan(void *stream, const void *gathered, uint32_t world, uint32_t samples, const void *rows, uint32_t n,
                        void *range8, uint32_t *splitters, uint32_t *dest, uint32_t *hist, uint32_t *owner_counts,
                        int coord_bytes);
-/* col_partition_group (2 launches): stable grouping by owner (one radix scatter of (dest, iota) into
- * (owners_sorted, perm); iota = 0, 1, 2, ...), then packing: the rows this rank keeps go to the front of
+/* col_partition_group (1 launch): stable grouping by owner and packing in one pass over the rows (dest / hist /
+ * owner_counts as col_partition_plan left them; world <= 16): the rows this rank keeps go to the front of
  * own_rows / own_gids / own_radii (`capacity` rows each); the others into `send`: one SLOT of 1 + slot transport
  * records per other rank (rank order) -- a header record whose first word is the full length of the list, then
  * min(length, slot) records.  Rows of a list beyond its slot STAY with this rank: they follow the kept rows in the
  * owned arrays (owner order), so a slot that is too small never loses a sphere (ownership only decides load
  * balance and halo size).  flags[2] = max(flags[2], longest list). */
 int col_partition_group(void *stream, const void *rows, const uint32_t *gids, uint32_t n, const uint32_t *dest,
-                        const uint32_t *iota, const uint32_t *hist, const uint32_t *owner_counts, uint32_t world,
-                        uint32_t rank, uint32_t slot, uint32_t *owners_sorted, uint32_t *perm, void *send, void *own_rows,
-                        uint32_t *own_gids, void *own_radii, uint32_t capacity, uint32_t *flags, int coord_bytes);
+                        const uint32_t *hist, const uint32_t *owner_counts, uint32_t world, uint32_t rank,
+                        uint32_t slot, void *send, void *own_rows, uint32_t *own_gids, void *own_radii,
+                        uint32_t capacity, uint32_t *flags, int coord_bytes);
 /* col_partition_unpack (1 launch): recv = the slots received from the other ranks (laid out as `send`) appended to
  * the owned arrays behind the rows col_partition_group left there (owner_counts[rank] kept rows + the overflow of
  * the lists it sent: sum over q != rank of max(owner_counts[q] - slot, 0)); a received header longer than the slot

@@ -116,18 +116,15 @@ def test_partition_group_and_unpack(hip_env, oracle, dt, world, rank, slot):
     counts = np.bincount(dest, minlength=world)
     cap = n + 5000
     others = max(1, world - 1)
-    b = dict(rows=upload(ctx, rows), gids=upload(ctx, gids), iota=upload(ctx, np.arange(n, dtype=np.uint32)),
-             owners=hip.Buffer(ctx, 4 * n), perm=hip.Buffer(ctx, 4 * n),
+    b = dict(rows=upload(ctx, rows), gids=upload(ctx, gids),
              send=upload(ctx, np.full(others * (slot + 1) * rw, 0xABABABAB, np.uint32)),
              own_rows=upload(ctx, np.zeros((cap, 4), dt)), own_gids=upload(ctx, np.zeros(cap, np.uint32)),
              own_radii=upload(ctx, np.zeros(cap, dt)), flags=upload(ctx, np.zeros(4, np.uint32)),
              owned=upload(ctx, np.zeros(2, np.uint32)))
-    call.col_partition_group(cq.stream, b["rows"].ptr, b["gids"].ptr, n, bufs["dest"].ptr, b["iota"].ptr, bufs["hist"].ptr,
-                             bufs["counts"].ptr, world, rank, slot, b["owners"].ptr, b["perm"].ptr, b["send"].ptr,
+    call.col_partition_group(cq.stream, b["rows"].ptr, b["gids"].ptr, n, bufs["dest"].ptr, bufs["hist"].ptr,
+                             bufs["counts"].ptr, world, rank, slot, b["send"].ptr,
                              b["own_rows"].ptr, b["own_gids"].ptr, b["own_radii"].ptr, cap, b["flags"].ptr, cb)
-    perm = np.argsort(dest, kind="stable")
-    np.testing.assert_array_equal(download(cq, b["perm"], np.uint32, n), perm)
-    np.testing.assert_array_equal(download(cq, b["owners"], np.uint32, n), dest[perm])
+    perm = np.argsort(dest, kind="stable")                     # (the grouping is stable: lists keep the input order)
     kept = perm[dest[perm] == rank]
     stay = np.concatenate([kept] + [perm[dest[perm] == q][slot:] for q in range(world) if q != rank])
     if slot == 100:

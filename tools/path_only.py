@@ -1,5 +1,6 @@
 """Runs only the single-GPU path a few times, for rocprofv3 passes.
-    python tools/path_only.py [steps] [n_spheres] [plan: auto|lsd|msd] [scene: uniform|config3]"""
+    python tools/path_only.py [steps] [n_spheres] [plan: auto|lsd|msd] [scene: uniform|config3] [leaf-block k] [traverse variant]
+(leaf-block k: col_debug_leaf_blocks, 0 = no marks; traverse variant: col_debug_traverse, 128 = the walk without block code)"""
 import os
 import sys
 
@@ -23,6 +24,14 @@ else:
     cap = bench.PAIR_CAPACITY * 8
 cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
 nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
+if len(sys.argv) > 5:
+    import ctypes
+    from collision_amd._lib import cdll
+    lib = cdll()
+    lib.col_debug_leaf_blocks.argtypes = [ctypes.c_float]
+    lib.col_debug_leaf_blocks(ctypes.c_float(float(sys.argv[5])))
+    if len(sys.argv) > 6:
+        lib.col_debug_traverse(int(sys.argv[6]))
 col = Collider(ctx, n, bench.NGROUPS, bench.GROUP_SIZE)
 col.sort_plan = plan
 for _ in range(steps):

@@ -3,7 +3,7 @@
 # profiles/ files of round $ROUND (default r02).
 set -e
 cd "$(dirname "$0")/.."
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-pmc   (MI355X, default K=50 W=10; summarised by"
   echo "# tools/summarize_prof.py from the rocpd results db).  k_scatter<unsigned int, 4, 16, 512, false> aggregates every launch of"
   echo "# the 64 Mi-pair instance in the run: the roofline leg's pass-0 and pass-3 series (cold + warm-up + timed), and all four digit"
