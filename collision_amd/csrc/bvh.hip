@@ -838,6 +838,8 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     // (variant bit 1): 0.112 ms.
     if (g_traverse_variant & 4) g = dim3(blocks > 256 ? 256 : blocks);
     if (g_traverse_variant & 16) mode |= 8;       // plain packet order
+    if (g_traverse_variant & 256) mode |= 1;      // timing ablation: skip phase 1 (pairs inside the packets)
+    if (g_traverse_variant & 512) mode |= 2;      // timing ablation: skip phase 2 (the walk)
     // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
     const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
     if ((g_traverse_variant & 255) == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
