@@ -245,7 +245,11 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         V4 c;
         T r;
         if (packed) {                 // (x, y, z, r) rows written by col_morton_ex: one gather per leaf
-            c = reinterpret_cast<const V4 *>(packed)[gid];
+            if (dbg & 16) {               // (timing ablation: the gather as a non-temporal load)
+                typedef T vec4 __attribute__((ext_vector_type(4)));
+                const vec4 v = __builtin_nontemporal_load(reinterpret_cast<const vec4 *>(packed) + gid);
+                c.x = v.x; c.y = v.y; c.z = v.z; c.w = v.w;
+            } else c = reinterpret_cast<const V4 *>(packed)[gid];
             r = c.w;
         } else {
             c = reinterpret_cast<const V4 *>(coords)[gid];

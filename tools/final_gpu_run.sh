@@ -13,8 +13,8 @@ if [ "$1" = "tests" ]; then
     tail -14 $O/final_tests.log
     timeout -k 10 300 python bench.py > $O/bench_final.json 2> $O/bench_final.err || { tail -20 $O/bench_final.err; exit 1; }
     echo "bench ok"
-    COLLISION_BENCH_BACKEND=gloo timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-        --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 --no-radix > $O/bench_g2.json 2> $O/bench_g2.err \
+    # typed as a plain command: bench.py starts its own torch.distributed.run (gloo here: both ranks share this box's GPU)
+    COLLISION_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 --no-radix > $O/bench_g2.json 2> $O/bench_g2.err \
         || { tail -20 $O/bench_g2.err; exit 1; }
     echo "gloo N=2 rehearsal ok"
     exit 0
@@ -41,3 +41,9 @@ for c in "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUP
         || { tail -20 $O/path_pmc_$i.log; exit 1; }
 done
 echo "path pmc ok"
+bash $R/tools/profile_hbm_regime.sh || exit 1
+bash $R/tools/profile_traverse_r3.sh || exit 1
+cd $R
+timeout -k 10 200 python tools/config4_loopback.py morton > $O/config4_morton.log 2>&1 || { tail -20 $O/config4_morton.log; exit 1; }
+timeout -k 10 200 python tools/config4_loopback.py hash > $O/config4_hash.log 2>&1 || { tail -20 $O/config4_hash.log; exit 1; }
+echo "config 4 loopback ok"
