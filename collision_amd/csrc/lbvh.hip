@@ -50,11 +50,22 @@ template <typename T> __device__ __forceinline__ Box<T> box_empty() {
     for (int a = 0; a < 3; a++) { b.lo[a] = (T)INFINITY; b.hi[a] = -(T)INFINITY; }
     return b;
 }
+// min / max as ONE instruction.  `o < a ? o : a` compiles to v_cmp + two wait states + v_cndmask on gfx950 (a VALU
+// instruction may not read an SGPR mask a VALU instruction has just written), and box unions are a third of k_chunk's
+// vector instructions.  v_min / v_max return the same bits as the compare-and-select for every pair of ordinary
+// numbers; they differ only where the reference's own `min(x, y)` (collision.cl:157: "y < x ? y : x") depends on the
+// ORDER of its arguments -- a tie between +0 and -0 (the instruction: -0 for min, +0 for max, whatever the order) and
+// NaN coordinates (ignored unless both are NaN) -- i.e. where a range-query refit could not promise the tree-order
+// result anyway; no fixture of the reference has either.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hw_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hw_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <typename T> __device__ __forceinline__ void box_merge(Box<T> &a, const Box<T> &o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        a.lo[k] = o.lo[k] < a.lo[k] ? o.lo[k] : a.lo[k];
-        a.hi[k] = o.hi[k] > a.hi[k] ? o.hi[k] : a.hi[k];
+        a.lo[k] = hw_min(a.lo[k], o.lo[k]);
+        a.hi[k] = hw_max(a.hi[k], o.hi[k]);
     }
 }
 
