@@ -107,6 +107,9 @@ _PROTOS = {
                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_traverse_chunked_scratch_bytes": (C.c_size_t, []),
+    "col_traverse_chunked": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                    C.c_void_p]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_leaf_blocks": (C.c_int, [C.c_float]),

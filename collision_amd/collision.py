@@ -72,6 +72,12 @@ class Collider:
         # period).  sort_plan = "lsd" / "msd" pins the choice (a captured
         # hipGraph replays whichever plan the captured call chose: pin "lsd" for clustered scenes).
         self.sort_plan = "auto"
+        # Pair-list allocation of the traversal: "exact" = every wave reserves its 512 staged pairs with one atomic on
+        # the pair counter; "chunked" = workgroups reserve 8192 at a time and a small kernel closes the holes (scenes
+        # with millions of pairs: one address retires ~88 atomics/us, BASELINE config 3 needs 50 000).  "auto": chunked
+        # when the PREVIOUS call on the same counter buffer found more than DENSE_PAIRS pairs (each call publishes
+        # the count it is about to zero in a host-visible word: no launch, no sync).
+        self.traverse_plan = "auto"
         self._plan_word = None
         self._lsd_calls_left = 0
         self._retry_after = self.PLAN_RETRY
@@ -142,21 +148,38 @@ class Collider:
             self._codes_bufs[0].ptr, self._codes_bufs[1].ptr, self._ids_bufs[0].ptr, self._ids_bufs[1].ptr,
             self._nodes_buf.ptr, self._bounds_buf.ptr, None, self._alloc["scratch"].ptr,
             n_collisions_buf.ptr, None if collisions_buf is None else collisions_buf.ptr, n_collisions,
-            self._choose_sort_plan(), self._plan_word)
+            self._choose_plan(n_collisions), self._plan_word)
         return hip.Event(cq)
 
     PLAN_RETRY, PLAN_RETRY_MAX = 64, 4096
+    DENSE_PAIRS = 6000000           # previous pair count from which the traversal allocates in chunks (break-even ~5 M:
+                                    # 0.374 / 0.400 ms exact / chunked at 3.3 M pairs, 0.85 / 0.60 ms at 25.4 M)
+
+    def _choose_plan(self, capacity=0):
+        """sort_plan argument of col_collide_plan: bit 0 = the sort (0 LSD, 1 MSD), bit 1 = chunked pair allocation.
+        Chunked allocation leaves up to 512 x 8192 list slots unused until its last kernel closes them; a list that does
+        not have that much room beyond the expected count would have to be rebuilt the exact way, so "auto" only
+        chooses it with the room (or in count-only mode, capacity 0)."""
+        if self._plan_word is None:      # three host-visible words the device reports into (include/collision_hip.h)
+            word = C.c_void_p()
+            call.col_host_alloc(C.byref(word), 64)
+            self._plan_word = word.value
+            for k in range(3):
+                C.c_uint32.from_address(self._plan_word + 4 * k).value = 0
+        plan = self._choose_sort_plan()
+        if self.traverse_plan == "chunked":
+            return plan | 2
+        if self.traverse_plan == "auto" and self._plan_word:
+            last = C.c_uint32.from_address(self._plan_word + 8).value
+            if last & 0x80000000 and (last & 0x7FFFFFFF) >= self.DENSE_PAIRS and \
+                    (capacity == 0 or capacity >= (last & 0x7FFFFFFF) + 512 * 8192):
+                return plan | 2
+        return plan
 
     def _choose_sort_plan(self):
         """0 = LSD, 1 = MSD (see __init__)."""
         if self.sort_plan == "lsd":
             return 0
-        if self._plan_word is None:
-            word = C.c_void_p()
-            call.col_host_alloc(C.byref(word), 64)
-            self._plan_word = word.value
-            C.c_uint32.from_address(self._plan_word).value = 0
-            C.c_uint32.from_address(self._plan_word + 4).value = 0
         if self.sort_plan == "msd":          # pinned: the kernel still reports an oversize bucket (self.oversize_bucket)
             return 1
         flag = C.c_uint32.from_address(self._plan_word)

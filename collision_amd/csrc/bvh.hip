@@ -239,6 +239,10 @@ __global__ __launch_bounds__(256) void k_refit_finish(T *__restrict__ bounds, u3
 constexpr int TW = 16;            // waves per block
 constexpr int TT = TW * 64;       // 1024 threads
 constexpr int CAPW = 512;         // staged pairs per wave (2 KB)
+constexpr int CHUNK_PAIRS = 8192;  // list slots a block takes from the global counter at a time (chunked allocation)
+// header + one hole per block of the chunked allocation (col_traverse_chunked): done = blocks finished (the last one sums up),
+// A = slots allocated, T = pairs found, overflow = A > capacity (the list cannot be closed: the exact walk runs again)
+struct ChunkHdr { u32 done, A, T, overflow, pad[12]; uint2 holes[512]; };
 
 struct PairSink {
     uint2 *buf;        // this wave's LDS staging area
@@ -259,7 +263,58 @@ struct PairSink {
             }
         }
     }
+    // CHUNKED allocation (dense scenes): one address retires ~88 atomics/us, and a scene with 25 M pairs flushes 50 000
+    // times -- 0.28 of config 3's 0.64 ms traversal were the pair counter.  `chunk` (LDS, one word per block:
+    // end << 32 | cursor) is the block's current chunk of CHUNK_PAIRS list slots, taken from the global counter with ONE
+    // atomic; waves reserve their 512-pair pieces from it with LDS atomics.  The wave whose reservation crosses the
+    // chunk's end fills what is left, takes the next chunk and installs it with its own remainder already reserved (no
+    // slot is lost inside a chunk); waves that find the chunk exhausted wait for that.  What a block does not use of its
+    // LAST chunk is a hole in the list, recorded at the end of the kernel and closed by k_pairs_compact.
+    unsigned long long *chunk;     // NULL: every flush reserves from the global counter itself
+
+    __device__ __forceinline__ void copy_part(u32 from, u32 base, u32 cnt) {      // staged [from, from + cnt) -> list [base, ...)
+        for (u32 i = lane; i < cnt; i += 64) {
+            const u32 k = base + i;
+            if (k < capacity) {
+                uint2 pr = buf[from + i];
+                if (gids) pr.y = gids[pr.y];
+                *reinterpret_cast<uint2 *>(pairs + 2ull * k) = pr;
+            }
+        }
+    }
     __device__ __forceinline__ void flush() {          // wave-level, count > 0
+        if (chunk) {
+            u32 done = 0;
+            while (done < count) {
+                const u32 want = count - done;
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(chunk, (unsigned long long)want);
+                const u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+                const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+                if (cur + want <= end) {                         // it fits
+                    copy_part(done, cur, want);
+                    done = count;
+                } else if (cur <= end) {                         // the one reservation that crosses the end
+                    const u32 r = end - cur;
+                    copy_part(done, cur, r);
+                    done += r;
+                    const u32 rest = count - done;
+                    u32 nb = 0;
+                    if (lane == 0) {
+                        nb = atomicAdd(counter, (u32)CHUNK_PAIRS);
+                        atomicExch(chunk, ((unsigned long long)(nb + (u32)CHUNK_PAIRS) << 32) | (nb + rest));
+                    }
+                    nb = (u32)__builtin_amdgcn_readfirstlane((int)nb);
+                    copy_part(done, nb, rest);
+                    done = count;
+                } else {                                         // exhausted: the crossing wave installs the next chunk
+                    while ((u32)(__hip_atomic_load(chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == end)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            count = 0;
+            return;
+        }
         u32 base = 0;
         if (lane == 0) base = atomicAdd(counter, count);
         base = (u32)__builtin_amdgcn_readfirstlane((int)base);
@@ -322,8 +377,10 @@ struct NoGhost {};
 template <bool G> struct GhostSel { typedef NoGhost T; };
 template <> struct GhostSel<true> { typedef GhostArgs T; };
 
+// (amdgpu_num_sgpr(80): above 80 only ONE 16-wave block fits a CU on this platform -- see the SGPR note at the asm walk;
+// what does not fit is spilled to VGPR lanes, of which there are plenty)
 template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false>
-__global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
+__global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode, typename GhostSel<GHOST>::T ghost = {}) {
     typedef typename BTypes<T>::V4 V4;
@@ -336,7 +393,19 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
     const u32 leaf_start = n - 1;
     const bool marks = n <= COL_LEAF_BLOCK_MAX_N;      // internal nodes over <= 16 leaves carry leaf-block marks
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
-    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr};
+    __shared__ unsigned long long s_chunk;
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr, nullptr};
+    // mode bit 6: run only if the chunked walk before this launch could not close its list (ChunkHdr::overflow);
+    // mode bit 5: chunked allocation, `stats` is the ChunkHdr
+    if (!STATS && (mode & 64) && reinterpret_cast<const ChunkHdr *>(stats)->overflow == 0) return;
+    if (!STATS && (mode & 32)) {
+        if (threadIdx.x == 0) s_chunk = 0;
+        __syncthreads();
+        sink.chunk = &s_chunk;
+    }
+    // (timing ablation, mode bit 4: every wave flushes through a counter of its own -- what the walk costs without the
+    // contention of 50 k atomics on ONE address; the pair list is then garbage)
+    if (!STATS && (mode & 16) && stats) sink.counter = reinterpret_cast<u32 *>(stats) + 32u * ((blockIdx.x * TW + w) & 8191u);
     u32 npackets = (n + 63) / 64;
     if constexpr (GHOST) {
         sink.gids = ghost.gids;
@@ -736,6 +805,42 @@ __global__ __launch_bounds__(TT) void k_traverse(u32 *__restrict__ pairs, u32 *_
         }
     }
 
+    if (!STATS && sink.chunk) {
+        // chunked allocation: the leftovers go the same way; then the block records what it leaves unused of its last
+        // chunk, and the LAST block to get here sums up: T = slots allocated - holes = the number of pairs
+        if (sink.count) sink.flush();
+        __syncthreads();
+        ChunkHdr *hdr = reinterpret_cast<ChunkHdr *>(stats);
+        __shared__ u32 s_last;
+        if (threadIdx.x == 0) {
+            const unsigned long long v = s_chunk;
+            const u32 cur = (u32)v, end = (u32)(v >> 32);
+            hdr->holes[blockIdx.x] = make_uint2(cur, end - cur);
+            __threadfence();
+            s_last = atomicAdd(&hdr->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            u32 sum = 0;
+            for (u32 i = threadIdx.x; i < gridDim.x; i += TT) sum += __hip_atomic_load(&hdr->holes[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum = wave_sum(sum);
+            if (lane == 0) s_cnt[w] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u32 holes = 0;
+                for (int i = 0; i < TW; i++) holes += s_cnt[i];
+                const u32 A = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 over = capacity > 0 && (A > capacity || A > (1u << 29)) ? 1u : 0u;      // (count-only: nothing is stored, nothing to close)
+                hdr->A = A;
+                hdr->T = A - holes;
+                hdr->overflow = over;
+                hdr->done = 0;
+                *counter = over ? 0u : A - holes;         // the exact walk counts again from zero
+            }
+        }
+        return;
+    }
     // block-level flush of what is still staged: one atomic for the 16 waves
     if (lane == 0) s_cnt[w] = sink.count;
     __syncthreads();
@@ -777,7 +882,7 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
     const u32 leaf_start = n - 1;
     const bool marks = n <= COL_LEAF_BLOCK_MAX_N;
     const V4 *rows = reinterpret_cast<const V4 *>(bounds);
-    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr};
+    PairSink sink = {s_buf[w], 0u, pairs, counter, capacity, lane, nullptr, nullptr};
     const u32 npackets = (n + 63) / 64;
     for (u32 packet = blockIdx.x * TW + w; packet < npackets; packet += gridDim.x * TW) {
         const u32 q = packet * 64 + lane;
@@ -840,15 +945,141 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     if (g_traverse_variant & 16) mode |= 8;       // plain packet order
     if (g_traverse_variant & 256) mode |= 1;      // timing ablation: skip phase 1 (pairs inside the packets)
     if (g_traverse_variant & 512) mode |= 2;      // timing ablation: skip phase 2 (the walk)
+    static u64 *spread = nullptr;                  // timing ablation: per-wave flush counters (variant bit 10)
+    if (g_traverse_variant & 1024) {
+        if (!spread && hipMalloc((void **)&spread, 8192 * 32 * 4) != hipSuccess) return COL_EINVAL;
+        mode |= 16;
+    }
     // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
     const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
     if ((g_traverse_variant & 255) == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
     else if (st) k_traverse<T, true, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (g_traverse_variant & 2) k_traverse<T, false, true, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (off32 && (g_traverse_variant & 128)) k_traverse<T, false, false, 2><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (g_traverse_variant & 1024) ? spread : st, mode);
     else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
+    return COL_OK;
+}
+
+// Closes the holes a chunked walk left in the pair list (ChunkHdr): the list occupies [0, A) with one hole per block --
+// the unused end of its last chunk -- and T = A - (all holes) pairs; the pairs that lie at or beyond T move into the hole
+// slots below T (there are exactly as many of one as of the other), which leaves the dense list [0, T).  Every block sorts
+// the <= 512 holes by position for itself (rank by counting), then thread k moves the k-th pair.
+__global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, const ChunkHdr *__restrict__ hdr, u32 nholes) {
+    __shared__ u32 s_start[512], s_len[512];
+    __shared__ u32 s_low[513], s_fill[513];       // exclusive prefixes: hole slots below T; pairs at / beyond T before hole i
+    __shared__ u32 s_b[513], s_e[513];
+    if (hdr->overflow) return;
+    const u32 A = hdr->A, T = hdr->T, tid = threadIdx.x;
+    if (A == T) return;                            // no holes
+    // sort the holes by position without sorting: every chunk starts at a multiple of CHUNK_PAIRS (the counter only ever
+    // grows by whole chunks) and holds at most one hole, so a bitmap over the chunk numbers ranks them (popcounts)
+    __shared__ unsigned long long s_bits[1024];          // 65 536 chunks = 2^29 pairs; longer lists count as overflow
+    __shared__ u32 s_wpre[1024];
+    __shared__ u32 s_ws2[4];
+    for (u32 i = tid; i < 1024; i += 256) s_bits[i] = 0;
+    for (u32 i = tid; i < 513; i += 256) { if (i < 512) { s_start[i] = A; s_len[i] = 0; } }
+    __syncthreads();
+    uint2 mine[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const u32 i = tid + 256 * u;
+        mine[u] = i < nholes ? hdr->holes[i] : make_uint2(0u, 0u);
+        if (mine[u].y) {
+            const u32 c = mine[u].x / (u32)CHUNK_PAIRS;
+            atomicOr(&s_bits[c >> 6], 1ull << (c & 63u));
+        }
+    }
+    __syncthreads();
+    {
+        u32 pc[4], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pc[u] = (u32)__popcll(s_bits[4 * tid + u]); sum += pc[u]; }
+        u32 total;
+        u32 run = block_excl_scan<256>(sum, s_ws2, &total);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { s_wpre[4 * tid + u] = run; run += pc[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (mine[u].y) {
+            const u32 c = mine[u].x / (u32)CHUNK_PAIRS;
+            const u32 rank = s_wpre[c >> 6] + (u32)__popcll(s_bits[c >> 6] & ((1ull << (c & 63u)) - 1ull));
+            s_start[rank] = mine[u].x; s_len[rank] = mine[u].y;
+        }
+    __syncthreads();
+    {   // exclusive prefixes over the 512 sorted holes, two per thread
+        __shared__ u32 s_ws[4];
+        u32 lowc[2], highc[2], bb[2], ee[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const u32 i = 2 * tid + u;
+            const u32 st = s_start[i], ln = s_len[i];
+            bb[u] = ln ? (st > T ? st : T) : A;                          // the hole's part at / beyond T: [b, e)
+            ee[u] = ln ? (st + ln > T ? st + ln : T) : A;
+            lowc[u] = ln ? (st >= T ? 0u : (st + ln <= T ? ln : T - st)) : 0u;      // its slots below T
+            highc[u] = ee[u] - bb[u];
+        }
+        u32 total_low, total_high;
+        const u32 plow = block_excl_scan<256>(lowc[0] + lowc[1], s_ws, &total_low);
+        const u32 phigh = block_excl_scan<256>(highc[0] + highc[1], s_ws, &total_high);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const u32 i = 2 * tid + u;
+            const u32 lo_before = plow + (u ? lowc[0] : 0u), hi_before = phigh + (u ? highc[0] : 0u);
+            s_low[i] = lo_before;
+            s_b[i] = bb[u]; s_e[i] = ee[u];
+            s_fill[i] = (bb[u] - T) - hi_before;                          // pairs in [T, b)
+        }
+        if (tid == 0) {
+            s_low[512] = total_low;
+            s_fill[512] = (A - T) - total_high;                           // = the number of pairs to move = total_low
+            s_b[512] = A; s_e[512] = A;
+        }
+    }
+    __syncthreads();
+    const u32 moves = s_low[512];
+    for (u32 k = blockIdx.x * 256 + tid; k < moves; k += gridDim.x * 256) {
+        // destination: the k-th hole slot below T
+        u32 lo = 0, hi = 511;                      // last i with s_low[i] <= k
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_low[mid] <= k) lo = mid; else hi = mid - 1; }
+        const u32 dst = s_start[lo] + (k - s_low[lo]);
+        // source: the k-th pair at / beyond T: behind the last hole i with s_fill[i] <= k, or before the first one
+        u32 src;
+        if (k < s_fill[0]) src = T + k;
+        else {
+            lo = 0; hi = 511;
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_fill[mid] <= k) lo = mid; else hi = mid - 1; }
+            src = s_e[lo] + (k - s_fill[lo]);
+        }
+        *reinterpret_cast<uint2 *>(pairs + 2ull * dst) = *reinterpret_cast<const uint2 *>(pairs + 2ull * src);
+    }
+}
+
+// The walk with chunked pair allocation (dense scenes), for lists that start at *counter == 0: four launches -- clear the
+// header, walk, close the holes, and the exact walk again, which returns at once unless the chunks ran past `capacity`
+// (the list could then not be closed and is rebuilt the exact way: still min(count, capacity) valid pairs).
+template <typename T>
+int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
+                            uint32_t n, void *scratch) {
+    const u32 npackets = (n + 63) / 64;
+    u32 blocks = (u32)col_ceil_div(npackets, TW);
+    if (blocks > 512) blocks = 512;
+    dim3 g(blocks), t(TT);
+    hipStream_t s = col_stream(stream);
+    const T *bd = (const T *)bounds;
+    ChunkHdr *hdr = (ChunkHdr *)scratch;
+    COL_HIP(hipMemsetAsync(hdr, 0, 64, s));
+    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32);
+    COL_LAUNCH_OK();
+    if (capacity) {
+        k_pairs_compact<<<dim3(512), dim3(256), 0, s>>>(pairs, hdr, blocks);
+        COL_LAUNCH_OK();
+        k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 64);
+        COL_LAUNCH_OK();
+    }
     return COL_OK;
 }
 
@@ -937,6 +1168,22 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     return COL_EINVAL;
 }
 
+size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
+
+// col_traverse for scenes with millions of pairs: the same pair list, but the workgroups take list space in chunks of
+// 8192 pairs (one atomic on the counter per chunk instead of one per 512 pairs) and a small kernel closes the holes at
+// the end.  *counter must be 0 on entry (the list starts here).  f32 coordinates and record arrays below 4 GB (what the
+// asm walk needs); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
+int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
+                         const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
+    const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32);
+    if (coord_bytes != 4 || !off32 || !scratch || g_traverse_variant)
+        return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
+    if (n < 2) return COL_OK;
+    if (capacity > 0 && !pairs) return COL_EINVAL;
+    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch);
+}
+
 // Diagnostics: same traversal, also accumulates stats[0..7] (8 x u64) = phase-2 steps, descents, leaf
 // tests, leaf hits, and the steps within 1k / 2k / 4k / 8k sorted positions of the block's first leaf.  mode bit0 skips phase 1, bit1 skips phase 2 (timing ablations only).
 int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
@@ -950,7 +1197,7 @@ int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_
 size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
     return 256 /* scene range */ + col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4) +
            col_radix_scratch_bytes(padded, 4, 4) + col_lbvh_scratch_bytes(n, coord_bytes) +
-           (size_t)n * 4 * coord_bytes /* packed (x,y,z,r) rows */ + 1024;
+           (size_t)n * 4 * coord_bytes /* packed (x,y,z,r) rows */ + sizeof(ChunkHdr) + 256 /* chunked pair allocation */ + 1024;
 }
 
 int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
@@ -995,7 +1242,13 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     void *lbvh_scratch = p;    p += col_lbvh_scratch_bytes(n, coord_bytes);
     p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    void *packed = p;
+    void *packed = p;          p += (size_t)n * 4 * coord_bytes;
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    void *chunk_hdr = p;
+    // sort_plan: bit 0 = the sort (COL_SORT_LSD / COL_SORT_MSD), bit 1 = COL_TRAVERSE_CHUNKED (dense scenes)
+    const bool chunked = (sort_plan & COL_TRAVERSE_CHUNKED) != 0;
+    sort_plan &= 1;
+    uint32_t *publish = oversize ? oversize + 2 : nullptr;      // the previous call's pair count, for the caller's next choice
     int rc;
     const uint32_t tile = col_radix_tile(padded, 4, 4);
     if (tile == 1024 || tile == 4096) {
@@ -1008,7 +1261,8 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
             partials = red_scratch;
         }
         if ((rc = col_morton_tile(stream, coords, radii, partials, parts, n, padded, coord_bytes, codes0, ids0, packed,
-                                  counter, (uint32_t *)sort_scratch, tile, (uint32_t)col_ceil_div(padded, tile), msd ? 22 : 0))) return rc;
+                                  counter, (uint32_t *)sort_scratch, tile, (uint32_t)col_ceil_div(padded, tile), msd ? 22 : 0,
+                                  publish))) return rc;
         if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;
@@ -1016,10 +1270,11 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
         if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_bucket_report(stream, codes1, padded, oversize + 1))) return rc;
     } else {
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
-        if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter))) return rc;
+        if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter, publish))) return rc;
         if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
     }
     if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
+    if (chunked) return col_traverse_chunked(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr);
     return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
 }
 

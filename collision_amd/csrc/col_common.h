@@ -22,7 +22,7 @@
 // internal entry points shared between translation units (not part of the public header)
 extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii, const void *range, uint32_t n,
                              uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                             uint32_t *zero_word);
+                             uint32_t *zero_word, uint32_t *publish);
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes);
 
@@ -46,7 +46,8 @@ extern "C" int col_minmax4_stage1_dev(void *stream, const void *rows, const uint
                                       void *partials, uint32_t *parts);
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                               uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift);
+                               uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift,
+                               uint32_t *publish);
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 

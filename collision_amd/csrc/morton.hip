@@ -14,14 +14,24 @@ namespace {
 template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T x, y, z, w; };
 template <> struct alignas(16) Vec4<double> { double x, y, z, w; };
 
+// The word that is about to be zeroed is the pair counter of the PREVIOUS call on the same buffers: publish it in a
+// host-visible word (0x80000000 | count) before it goes -- the host reads it when it makes its next call and chooses the
+// traversal's allocation scheme by it (dense scenes: chunked, bvh.hip), with no launch and no sync spent on it.
+__device__ __forceinline__ void publish_count(u32 *publish, u32 count) {
+    if (publish) __hip_atomic_store(publish, 0x80000000u | (count < 0x7FFFFFFFu ? count : 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coords,
                                                  const Vec4<T> *__restrict__ range, u32 n, u32 padded,
                                                  u32 *__restrict__ codes, u32 *__restrict__ ids,
                                                  const T *__restrict__ radii, Vec4<T> *__restrict__ packed,
-                                                 u32 *__restrict__ zero_word) {
+                                                 u32 *__restrict__ zero_word, u32 *publish) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && zero_word) *zero_word = 0;            // the pair counter (collision.py:151-154), no extra launch
+    if (i == 0 && zero_word) {                          // the pair counter (collision.py:151-154), no extra launch
+        publish_count(publish, *zero_word);
+        *zero_word = 0;
+    }
     if (i >= padded) return;
     u32 code = 0xFFFFFFFFu;   // collision.py:137-142
     if (i < n) {
@@ -50,12 +60,15 @@ __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ 
                                                      u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
                                                      u32 *__restrict__ ids, const T *__restrict__ radii,
                                                      Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
-                                                     u32 *__restrict__ hist0, u32 nblocks, int hist_shift) {
+                                                     u32 *__restrict__ hist0, u32 nblocks, int hist_shift, u32 *publish) {
     constexpr int TILE = NT * MT_ROWS, NW = NT / 64;
     __shared__ T s_fold[NW][8];
     __shared__ u32 s_hist[256];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0 && zero_word) *zero_word = 0;
+    if (blockIdx.x == 0 && tid == 0 && zero_word) {
+        publish_count(publish, *zero_word);
+        *zero_word = 0;
+    }
     if (tid < 256) s_hist[tid] = 0;
     // this thread's rows first: their loads overlap the fold of the partials below
     Vec4<T> c[MT_ROWS];
@@ -133,14 +146,14 @@ __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ 
 template <typename T>
 int launch_morton_tile(hipStream_t s, u32 tile, const void *coords, const void *radii, const void *partials, uint32_t parts,
                        uint32_t n, uint32_t padded, uint32_t *codes, uint32_t *ids, void *packed, uint32_t *zero_word,
-                       uint32_t *hist0, uint32_t nblocks, int hist_shift) {
+                       uint32_t *hist0, uint32_t nblocks, int hist_shift, uint32_t *publish) {
     dim3 grid(nblocks);
     if (tile == 1024)
         k_morton_tile<T, 256><<<grid, dim3(256), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                          (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift);
+                                                          (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
     else
         k_morton_tile<T, 1024><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                            (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift);
+                                                            (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -151,7 +164,7 @@ extern "C" {
 
 int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                     uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                    uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift) {
+                    uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift, uint32_t *publish) {
     if (padded < n || parts == 0 || !hist0 || hist_shift < 0 || hist_shift > 24) return COL_EINVAL;
     if (tile != 1024 && tile != 4096) return COL_EINVAL;
     if (padded == 0) return COL_OK;
@@ -159,27 +172,27 @@ int col_morton_tile(void *stream, const void *coords, const void *radii, const v
     if (nblocks != (uint32_t)col_ceil_div(padded, tile)) return COL_EINVAL;
     if (coord_bytes == 4)
         return launch_morton_tile<float>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
-                                         zero_word, hist0, nblocks, hist_shift);
+                                         zero_word, hist0, nblocks, hist_shift, publish);
     if (coord_bytes == 8)
         return launch_morton_tile<double>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
-                                          zero_word, hist0, nblocks, hist_shift);
+                                          zero_word, hist0, nblocks, hist_shift, publish);
     return COL_EINVAL;
 }
 
 // col_morton plus two by-products for col_collide: packed (x, y, z, r) rows and a zeroed word.
 int col_morton_ex(void *stream, const void *coords, const void *radii, const void *range, uint32_t n, uint32_t padded,
-                  int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed, uint32_t *zero_word) {
+                  int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed, uint32_t *zero_word, uint32_t *publish) {
     if (padded < n) return COL_EINVAL;
     if (padded == 0) return COL_OK;
     if (packed && !radii) return COL_EINVAL;
     dim3 grid((unsigned)col_ceil_div(padded, 256)), block(256);
     if (coord_bytes == 4)
         k_morton<float><<<grid, block, 0, col_stream(stream)>>>((const Vec4<float> *)coords, (const Vec4<float> *)range, n, padded,
-                                                                codes, ids, (const float *)radii, (Vec4<float> *)packed, zero_word);
+                                                                codes, ids, (const float *)radii, (Vec4<float> *)packed, zero_word, publish);
     else if (coord_bytes == 8)
         k_morton<double><<<grid, block, 0, col_stream(stream)>>>((const Vec4<double> *)coords, (const Vec4<double> *)range, n,
                                                                  padded, codes, ids, (const double *)radii, (Vec4<double> *)packed,
-                                                                 zero_word);
+                                                                 zero_word, publish);
     else
         return COL_EINVAL;
     COL_LAUNCH_OK();
@@ -188,7 +201,7 @@ int col_morton_ex(void *stream, const void *coords, const void *radii, const voi
 
 int col_morton(void *stream, const void *coords, const void *range, uint32_t n, uint32_t padded, int coord_bytes,
                uint32_t *codes, uint32_t *ids) {
-    return col_morton_ex(stream, coords, nullptr, range, n, padded, coord_bytes, codes, ids, nullptr, nullptr);
+    return col_morton_ex(stream, coords, nullptr, range, n, padded, coord_bytes, codes, ids, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

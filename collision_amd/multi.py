@@ -473,7 +473,7 @@ class HipEngine(ProtocolOps):
         call.col_collide_plan_partials(s, rows.data_ptr(), p["radii"], n, roundUp(n, 2 * self.group_size), self.cb,
                                        c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
                                        c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
-                                       p["counter"], p["pairs"], self.pair_capacity, c._choose_sort_plan(), c._plan_word,
+                                       p["counter"], p["pairs"], self.pair_capacity, c._choose_plan(self.pair_capacity), c._plan_word,
                                        partials, self._bounds_parts.value if partials else 0)
         call.col_translate_pairs(s, p["pairs"], p["counter"], 0, self.pair_capacity, gids.data_ptr())
 

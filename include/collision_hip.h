@@ -178,6 +178,15 @@ int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coord
 int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                  const col_node *nodes, const void *bounds, uint32_t n, int coord_bytes);
 
+/* col_traverse for scenes with millions of pairs (same list, same counter semantics): workgroups take list space in
+ * chunks of 8192 pairs -- one atomic on the counter per chunk instead of one per 512 pairs, which is what bounds the walk
+ * on BASELINE config 3 (50 000 atomics on one address) -- and a small kernel closes the holes the chunks leave; if the
+ * chunks ran past `capacity` the exact walk runs again (4 launches instead of 1).  *counter must be 0 on entry.
+ * f32 and record arrays below 4 GB; anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes(). */
+size_t col_traverse_chunked_scratch_bytes(void);
+int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
+                         const void *bounds, uint32_t n, int coord_bytes, void *scratch);
+
 /* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
  * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
@@ -229,7 +238,10 @@ int col_collide(void *stream, const void *coords, const void *radii, uint32_t n,
  *                 to COL_SORT_LSD.  A call that takes COL_SORT_LSD where the MSD plan could apply stores
  *                 0x80000000 | g to oversize[1], g = the largest MSD bucket of ITS codes (read off the sorted
  *                 codes): g above the bucket capacity means the MSD plan would have met an oversize bucket.
- *                 collision_amd.collision.Collider follows both on its own. */
+ *                 oversize[2] receives 0x80000000 | (the pair count the counter held when this call zeroed it,
+ *                 i.e. the PREVIOUS call's result on the same counter): a caller that sees millions of pairs
+ *                 there ORs COL_TRAVERSE_CHUNKED into sort_plan.  `oversize` is THREE words.
+ *                 collision_amd.collision.Collider follows all three on its own. */
 /* The MSD plan's sort on its own: (u32 code, u32 id) pairs, codes 30-bit or the 0xFFFFFFFF pad, n up to
  * 4 000 000.  The digit-major histogram of the bucket digit (bits 22..29) per col_radix_tile(n)-code tile --
  * what the fused Morton kernel leaves -- must be at the start of `scratch` (col_radix_scratch_bytes(n, 4, 4)). */
@@ -237,6 +249,9 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
                        uint32_t *vals_out, uint64_t n, void *scratch, uint32_t *oversize);
 #define COL_SORT_LSD 0
 #define COL_SORT_MSD 1
+/* ORed into sort_plan: the traversal takes pair-list space in chunks of 8192 pairs (col_traverse_chunked) -- for scenes
+ * with millions of pairs, where one atomic on the pair counter per 512 pairs is what bounds the walk.  Same list. */
+#define COL_TRAVERSE_CHUNKED 2
 int col_collide_plan(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded_size,
                      int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
                      col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,

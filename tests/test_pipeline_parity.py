@@ -28,18 +28,21 @@ def clustered_scene(n, sigma, r, dtype, seed=4):
     return pts.astype(dtype), np.full(n, r, dtype=dtype)
 
 
-def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=8, capacity=None, sort_plan=None):
+def check_against_oracle(oracle, hip_env, coords, radii, group_size=64, ngroups=8, capacity=None, sort_plan=None,
+                         traverse_plan=None, extra_capacity=0):
     ctx, cq = hip_env
     dt = coords.dtype
     n = len(coords)
     collider = Collider(ctx, n, ngroups, group_size, dt)
     if sort_plan is not None:
         collider.sort_plan = sort_plan
+    if traverse_plan is not None:
+        collider.traverse_plan = traverse_plan
     first_cap = capacity if capacity is not None else max(64 * n, min(n * (n - 1) // 2, 1 << 22))
     ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=first_cap)
     if capacity is None and ref["count"] > first_cap:          # dense scene: the oracle's list was cut short
         ref = oracle.collide(oracle.pad4(coords), radii, padded=collider.padded_size, capacity=ref["count"])
-    cap = ref["count"] if capacity is None else capacity
+    cap = ref["count"] + extra_capacity if capacity is None else capacity
     count, pairs = run_collider(ctx, cq, collider, coords, radii, cap)
     st = collider_state(cq, collider)
     np.testing.assert_array_equal(st["codes"], ref["codes"])
@@ -376,3 +379,66 @@ def test_leaf_blocks_do_not_change_the_result(hip_env, oracle, k, scene):
             check_against_oracle(oracle, hip_env, coords, radii, capacity=1000)
     finally:
         lib.col_debug_leaf_blocks(ctypes.c_float(3.0))
+
+
+@pytest.mark.parametrize("scene", ["clustered", "identical", "uniform_sparse", "two_blocks"])
+@pytest.mark.parametrize("room", ["exact", "ample", "tiny", "count_only"])
+def test_chunked_pair_allocation_gives_the_same_list(hip_env, oracle, scene, room):
+    """The traversal's chunked pair allocation (dense scenes: workgroups take list space 8192 pairs at a time, a small
+    kernel closes the holes) must give the same dense list as the exact one: with ample room (holes closed by
+    k_pairs_compact), with a buffer of exactly the pair count (the chunks run past it: the exact walk runs again), with
+    a buffer that is too small (min(count, capacity) valid distinct pairs, the counter counts everything) and in
+    count-only mode."""
+    if scene == "clustered":
+        coords, radii = clustered_scene(200000, 0.01, 0.002, "float32")       # ~ 10^7 pairs, every block allocates
+    elif scene == "identical":
+        coords, radii = np.full((3000, 3), 0.25, np.float32), np.full(3000, 0.01, np.float32)      # 4.5 M pairs from 47 packets
+    elif scene == "uniform_sparse":
+        coords, radii = uniform_scene(100000, 0.002, "float32")                # a few hundred pairs: almost only holes
+    else:
+        coords, radii = uniform_scene(1500, 0.05, "float32")                    # two workgroups
+    kw = dict(traverse_plan="chunked", group_size=256, ngroups=16)
+    if room == "exact":
+        check_against_oracle(oracle, hip_env, coords, radii, **kw)
+    elif room == "ample":
+        check_against_oracle(oracle, hip_env, coords, radii, extra_capacity=512 * 8192 + 1000, **kw)
+    elif room == "tiny":
+        _, _, count, pairs = check_against_oracle(oracle, hip_env, coords, radii, capacity=777, **kw)
+        ref = oracle.collide(oracle.pad4(coords), radii, capacity=max(count, 1))
+        got = pair_set(pairs)
+        assert len(pairs) == min(777, count) == len(got) and got <= pair_set(ref["pairs"])
+    else:
+        from collision_amd import hip
+        from tests.util import upload
+        ctx, cq = hip_env
+        collider = Collider(ctx, len(coords), 16, 256)
+        collider.traverse_plan = "chunked"
+        nb = hip.Buffer(ctx, 4)
+        e = collider.get_collisions(cq, upload(ctx, pad4(coords)), upload(ctx, radii), nb, None, 0)
+        count = int(hip.read_buffer(cq, nb, np.uint32, 1, wait_for=[e])[0])
+        assert count == oracle.collide(oracle.pad4(coords), radii, capacity=0, want=False)["count"]
+
+
+def test_dense_scenes_switch_to_chunked_allocation_on_their_own(hip_env, oracle):
+    """"auto": a call publishes the pair count it is about to zero; from DENSE_PAIRS pairs (and with room in the list) the
+    calls that follow allocate in chunks.  Exact lists throughout."""
+    from collision_amd import hip
+    from tests.util import upload
+    ctx, cq = hip_env
+    coords, radii = clustered_scene(200000, 0.01, 0.002, "float32")
+    ref = oracle.collide(oracle.pad4(coords), radii, capacity=0, want=False)
+    assert ref["count"] > 3000000
+    ref = oracle.collide(oracle.pad4(coords), radii, capacity=ref["count"])
+    cap = ref["count"] + 512 * 8192 + 4096
+    collider = Collider(ctx, len(coords), 16, 256)
+    collider.DENSE_PAIRS = 3000000
+    cb, rb, nb, pb = upload(ctx, pad4(coords)), upload(ctx, radii), hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
+    plans = []
+    choose = collider._choose_plan
+    collider._choose_plan = lambda capacity=0: plans.append(choose(capacity)) or plans[-1]
+    for _ in range(4):
+        collider.get_collisions(cq, cb, rb, nb, pb, cap)
+        cq.finish()
+        assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == ref["count"]
+        assert_same_pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2)), ref["pairs"])
+    assert [p & 2 for p in plans] == [0, 0, 2, 2], plans          # call k's count is published by call k + 1, seen by call k + 2

@@ -14,7 +14,7 @@ for name, (coords, radii), cap in (("uniform", bench.uniform_scene(n), 1 << 17),
     nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
     col = Collider(ctx, n, 64, 256)
     col.sort_plan = "lsd" if name == "config3" else "auto"
-    for k, variant in ((3.0, 0), (3.0, 256), (3.0, 512), (3.0, 768), (0.0, 128), (3.0, 0)):
+    for k, variant in ((3.0, 0), (3.0, 1024), (3.0, 0), (3.0, 1024)):
         lib.col_debug_leaf_blocks(ctypes.c_float(k))
         lib.col_debug_traverse(variant)
         def step():
