@@ -1,12 +1,15 @@
 #!/bin/bash
-# Round-end GPU runs (from the repo root on the GPU box).  Two gpurun calls, each within the 1200 s limit:
-#   bash tools/final_gpu_run.sh tests      GPU test suite, bench.py (default flags), N=2 gloo rehearsal of the bench
-#   bash tools/final_gpu_run.sh profiles   rocprofv3 kernel-trace stats of bench.py + PMC passes (radix 64 Mi, 1 M path)
-# tools/refresh_profiles.sh then condenses gpurun_out/ into the committed profiles/ files.
+# Round-end GPU runs (from the repo root on the GPU box).  Each mode is one gpurun call within the 1200 s limit:
+#   bash tools/final_gpu_run.sh tests       GPU test suite, bench.py (default flags), N=2 gloo rehearsal of the bench
+#   bash tools/final_gpu_run.sh profiles    rocprofv3 kernel-trace stats of bench.py + PMC passes (radix 64 Mi, 1 M path)
+#   bash tools/final_gpu_run.sh profiles2   the HBM-bound regime (2 M / 16 M), the traversal before / after leaf blocks, config 4
+# The rocprofv3 databases are condensed ON THE BOX (tools/summarize_prof.py) into gpurun_out/summary/ and deleted: gpurun
+# merges at most 64 MiB back.  tools/refresh_profiles.sh then copies the summaries into the committed profiles/ files.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-mkdir -p $O
+S=$O/summary
+mkdir -p $S
 cd $R
 if [ "$1" = "tests" ]; then
     timeout -k 10 800 python -m pytest tests -m gpu -x -q --durations=10 > $O/final_tests.log 2>&1 || { tail -30 $O/final_tests.log; exit 1; }
@@ -20,30 +23,81 @@ if [ "$1" = "tests" ]; then
     exit 0
 fi
 export TMPDIR=/tmp
-cd /tmp
-rm -rf $O/prof_bench $O/prof_pmc_* $O/path_pmc_*
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-pmc > $O/prof_bench.log 2>&1 \
-    || { tail -20 $O/prof_bench.log; exit 1; }
-echo "rocprof stats ok"
-for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
-    tag=${c%% *}
-    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d $O/prof_pmc_$tag -o pmc -- python3 $R/tools/radix_only.py 2 > $O/prof_pmc_$tag.log 2>&1 \
-        || { tail -20 $O/prof_pmc_$tag.log; exit 1; }
+pmc_pass() {      # pmc_pass <out dir> <counters> <script and args...>
+    local d=$1 c=$2; shift 2
+    rm -rf $d
+    ( cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python3 "$@" > $d.log 2>&1 ) || { tail -20 $d.log; exit 1; }
+}
+if [ "$1" = "profiles" ]; then
+    rm -rf $O/prof_bench
+    ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-pmc > $O/prof_bench.log 2>&1 ) \
+        || { tail -20 $O/prof_bench.log; exit 1; }
+    python tools/summarize_prof.py stats $O/prof_bench/bench_results.db > $S/bench_kernel_stats.txt && rm -rf $O/prof_bench
+    echo "rocprof stats ok"
+    dbs=""
+    for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+        tag=${c%% *}
+        pmc_pass $O/prof_pmc_$tag "$c" $R/tools/radix_only.py 2
+        dbs="$dbs $O/prof_pmc_$tag/pmc_results.db"
+    done
+    python tools/summarize_prof.py pmc $dbs > $S/radix64M_pmc.json && rm -rf $O/prof_pmc_*
+    echo "radix pmc ok"
+    i=0; dbs=""
+    for c in "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_DATA_READ_REQ SQC_TC_STALL" \
+             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM" \
+             "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH" \
+             "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i+1))
+        pmc_pass $O/path_pmc_$i "$c" $R/tools/path_only.py 10
+        dbs="$dbs $O/path_pmc_$i/pmc_results.db"
+    done
+    python tools/summarize_prof.py pmc $dbs > $S/path1M_pmc.json && rm -rf $O/path_pmc_*
+    echo "path pmc ok"
+    exit 0
+fi
+# profiles2
+for n in 2000000 16000000; do
+    tag=$((n / 1000000))M
+    rm -rf $O/hbm_${n}_stats
+    ( cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/hbm_${n}_stats -o kt -- python3 $R/tools/path_only.py 10 $n > $O/hbm_${n}_stats.log 2>&1 ) \
+        || { tail -20 $O/hbm_${n}_stats.log; exit 1; }
+    { echo "# rocprofv3 --kernel-trace --stats -- python3 tools/path_only.py 10 $n   (uniform scene, contacts per sphere of config 2)"
+      python tools/summarize_prof.py stats $O/hbm_${n}_stats/kt_results.db; } > $S/path${tag}_kernel_stats.txt
+    dbs=""
+    for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS"; do
+        t=${c%% *}
+        pmc_pass $O/hbm_${n}_$t "$c" $R/tools/path_only.py 6 $n
+        dbs="$dbs $O/hbm_${n}_$t/pmc_results.db"
+    done
+    python tools/summarize_prof.py pmc $dbs > $S/path${tag}_pmc.json && rm -rf $O/hbm_${n}_*
+    echo "n=$n ok"
 done
-echo "radix pmc ok"
-i=0
-for c in "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_DATA_READ_REQ SQC_TC_STALL" \
-         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM" \
-         "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH" \
-         "FETCH_SIZE" "WRITE_SIZE"; do
-    i=$((i+1))
-    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d $O/path_pmc_$i -o pmc -- python3 $R/tools/path_only.py 10 > $O/path_pmc_$i.log 2>&1 \
-        || { tail -20 $O/path_pmc_$i.log; exit 1; }
+# the traversal before / after leaf blocks and chunked allocation (before: no marks, the walk without block code)
+for scene in uniform config3; do
+  for tag in before after; do
+    extra=""; [ $tag = before ] && extra="0 128"
+    plan=auto; [ $scene = config3 ] && plan=lsd
+    i=0
+    for c in "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES"; do
+      i=$((i+1))
+      pmc_pass $O/trav_${scene}_${tag}_$i "$c" $R/tools/path_only.py 6 1000000 $plan $scene $extra
+    done
+  done
 done
-echo "path pmc ok"
-bash $R/tools/profile_hbm_regime.sh || exit 1
-bash $R/tools/profile_traverse_r3.sh || exit 1
-cd $R
+python - <<PY
+import json, subprocess, sys
+out = {}
+for scene in ("uniform", "config3"):
+    for tag in ("before", "after"):
+        dbs = ["$O/trav_%s_%s_%d/pmc_results.db" % (scene, tag, i) for i in (1, 2)]
+        d = json.loads(subprocess.check_output([sys.executable, "tools/summarize_prof.py", "pmc"] + dbs))
+        out["%s_%s" % (scene, tag)] = {k: {c: v["median"] for c, v in cs.items()} for k, cs in d.items() if "k_traverse" in k or "k_pairs" in k}
+json.dump(out, open("$S/traverse_leaf_blocks_pmc.json", "w"), indent=1, sort_keys=True)
+PY
+rm -rf $O/trav_*
+echo "traverse pmc ok"
 timeout -k 10 200 python tools/config4_loopback.py morton > $O/config4_morton.log 2>&1 || { tail -20 $O/config4_morton.log; exit 1; }
 timeout -k 10 200 python tools/config4_loopback.py hash > $O/config4_hash.log 2>&1 || { tail -20 $O/config4_hash.log; exit 1; }
+tail -1 $O/config4_morton.log > $S/config4_loopback_morton.json
+tail -1 $O/config4_hash.log > $S/config4_loopback_hash.json
 echo "config 4 loopback ok"
