@@ -111,6 +111,7 @@ _PROTOS = {
     "col_traverse_chunked": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                     C.c_void_p]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
+    "col_debug_walk_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_leaf_blocks": (C.c_int, [C.c_float]),
     "col_debug_radix": (C.c_int, [C.c_int]),

@@ -379,7 +379,11 @@ template <> struct GhostSel<true> { typedef GhostArgs T; };
 
 // (amdgpu_num_sgpr(80): above 80 only ONE 16-wave block fits a CU on this platform -- see the SGPR note at the asm walk;
 // what does not fit is spilled to VGPR lanes, of which there are plenty)
-template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false>
+// PROF (diagnostics, col_debug_traverse bit 12): every packet leaves the time of its phases (100 MHz clock) in
+// g_walk_prof[packet] = {phase 1, phase 2, loading its own leaf records, start tick (low word)}
+#define COL_PROF_PACKETS (1u << 18)
+__device__ uint4 g_walk_prof[COL_PROF_PACKETS];
+template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false, bool PROF = false>
 __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
                                                   int mode, typename GhostSel<GHOST>::T ghost = {}) {
@@ -423,10 +427,60 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
     const bool plain = (mode & 8) || gridDim.x < 8;
     u32 group = plain ? blockIdx.x : g_lo + slot;
     const u32 g_end = plain ? ngroups : g_hi, g_step = plain ? gridDim.x : slots;
-    for (; group < g_end; group += g_step) {
-        const u32 packet = group * TW + w;
-        if (packet >= npackets) continue;
+    // DYNAMIC PACKET ORDER (mode bit 8; `stats` = eight zeroed words, or the ChunkHdr with them in its pad): a wave's two
+    // packets of the static order take 7..38 us each on BASELINE config 2, so the kernel waits 55 us for the unluckiest
+    // waves while the packets' total is 30 us per wave slot (profiling instance, tools/walk3_ab.py).  Instead the
+    // workgroup draws batches of 16 consecutive packets from its XCD's counter (one global atomic per batch) and its waves
+    // take packets from the batch one by one (LDS word: end << 32 | cursor; the wave that finds cursor == end installs
+    // the next batch, later ones wait for it; end = ~0: the XCD's range is used up).
+    __shared__ unsigned long long s_sched;
+    const bool dyn = !STATS && !GHOST && (mode & 256) != 0 && !plain;
+    if (dyn) {
+        if (threadIdx.x == 0) s_sched = 0;
+        __syncthreads();
+    }
+    for (;;) {
+        u32 packet;
+        if (dyn) {
+            for (;;) {
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(&s_sched, 1ull);
+                const u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+                const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+                packet = END;
+                if (end == END) break;                                   // nothing left for this XCD
+                if (cur < end) { packet = cur; break; }
+                if (cur == end) {                                        // this wave draws the next batch
+                    // (the XCD's packet range and counter are worked out here, once per batch, rather than kept in registers:
+                    // the kernel has none to spare)
+                    const u32 x = blockIdx.x & 7u, ng = (npackets + TW - 1) / TW;
+                    const u32 p_lo = (u32)(((u64)ng * x) >> 3) * TW, p_hi = min((u32)(((u64)ng * (x + 1)) >> 3) * (u32)TW, npackets);
+                    u32 *sched_ctr = ((mode & 32) ? reinterpret_cast<ChunkHdr *>(stats)->pad : reinterpret_cast<u32 *>(stats)) + x;
+                    u32 nb = 0;
+                    if (lane == 0) nb = atomicAdd(sched_ctr, (u32)TW);
+                    nb = p_lo + (u32)__builtin_amdgcn_readfirstlane((int)nb);
+                    // (one store for both outcomes: two `if (lane == 0)` blocks with a `break` between them end in
+                    // "illegal VGPR to SGPR copy" in hipcc's backend)
+                    const bool none = nb >= p_hi;
+                    const u32 e = min(nb + (u32)TW, p_hi);
+                    const unsigned long long word = none ? 0xFFFFFFFF00000000ull : (((unsigned long long)e << 32) | (nb + 1u));
+                    if (lane == 0) atomicExch(&s_sched, word);
+                    packet = none ? END : nb;
+                    break;
+                }
+                while ((u32)__builtin_amdgcn_readfirstlane((int)(u32)(__hip_atomic_load(&s_sched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32)) == end)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            if (packet == END) break;
+        } else {
+            if (group >= g_end) break;
+            packet = group * TW + w;
+            group += g_step;
+            if (packet >= npackets) continue;
+        }
         const u32 q0 = packet * 64, q = q0 + lane;
+        u64 prof_t0 = 0, prof_t1 = 0, prof_t2 = 0;
+        if constexpr (PROF) prof_t0 = wall_clock64();
         T lx = (T)INFINITY, ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;      // empty box: overlaps nothing
         u32 qid = 0, qskip = END;
         if constexpr (GHOST) {
@@ -452,6 +506,10 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
             qid = (u32) * reinterpret_cast<const Bits *>(&b.w);
         }
         const int last = GHOST ? 0 : (int)min(63u, n - 1 - q0);        // wave-uniform: last valid lane
+        if constexpr (PROF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prof_t1 = wall_clock64();
+        }
         // phase 1: pairs inside the packet.  Exact float tests cost ~30 wave-instructions per pair
         // and almost all of them fail, so pairs are first screened with boxes quantised to 8 bits
         // per axis inside the packet's union box (lo rounded down, hi rounded up: a real overlap
@@ -538,6 +596,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
             round(32, true);
         }
 
+        if constexpr (PROF) prof_t2 = wall_clock64();
         // phase 2: everything after the packet's last leaf, one wave-uniform walk of the skip chain: one
         // 32-byte record per step at a wave-uniform address (scalar load), tested against the 64 query boxes.
         //
@@ -803,6 +862,11 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                 idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
         }
+        if constexpr (PROF) {
+            const u64 prof_t3 = wall_clock64();
+            if (lane == 0 && packet < COL_PROF_PACKETS)
+                g_walk_prof[packet] = make_uint4((u32)(prof_t2 - prof_t1), (u32)(prof_t3 - prof_t2), (u32)(prof_t1 - prof_t0), (u32)prof_t0);
+        }
     }
 
     if (!STATS && sink.chunk) {
@@ -923,10 +987,13 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
 }
 
 int g_traverse_variant = 0;       // diagnostics switch, see col_debug_traverse
+// from this many spheres on col_collide's traversal takes its packets in dynamic order (below it a wave has two packets
+// at most and the order changes nothing: 1 M 0.061 against 0.061 ms, 2 M 0.098 against 0.107, 16 M 0.74 against 0.90)
+#define COL_DYNAMIC_PACKETS_FROM 1500000u
 
 template <typename T>
 int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                    uint32_t n, uint64_t *stats, int mode) {
+                    uint32_t n, uint64_t *stats, int mode, uint32_t *sched = nullptr) {
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;               // 2 resident blocks of 16 waves per CU, grid-stride beyond
@@ -952,10 +1019,27 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     }
     // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
     const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
+    // dynamic packet order (k_traverse, mode bit 8): `sched` = eight zeroed words.  Variant bit 13 forces it (with
+    // counters of its own, cleared by a memset), bit 14 forbids it: the A/B switches of tools/walk3_ab.py
+    static u32 *dyn_sched = nullptr;
+    if ((g_traverse_variant & 8192) && !sched && !st && !(mode & (32 | 64))) {
+        if (!dyn_sched && hipMalloc((void **)&dyn_sched, 64) != hipSuccess) return COL_EINVAL;
+        COL_HIP(hipMemsetAsync(dyn_sched, 0, 64, s));
+        sched = dyn_sched;
+    }
+    if (sched && !st && !(g_traverse_variant & (16384 | 1 | 2 | 4 | 128 | 1024))) {      // (the other walks are A/B material)
+        mode |= 256;
+        if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
+        else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
+        else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
+        COL_LAUNCH_OK();
+        return COL_OK;
+    }
     if ((g_traverse_variant & 255) == 1) k_traverse_lane<T><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, 0);
     else if (st) k_traverse<T, true, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (g_traverse_variant & 2) k_traverse<T, false, true, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (off32 && (g_traverse_variant & 128)) k_traverse<T, false, false, 2><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (g_traverse_variant & 1024) ? spread : st, mode);
     else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     COL_LAUNCH_OK();
@@ -1064,6 +1148,8 @@ __global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, 
 template <typename T>
 int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                             uint32_t n, void *scratch) {
+    // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
+    const int dyn = (g_traverse_variant & 16384) ? 0 : 256;
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;
@@ -1072,7 +1158,7 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
     const T *bd = (const T *)bounds;
     ChunkHdr *hdr = (ChunkHdr *)scratch;
     COL_HIP(hipMemsetAsync(hdr, 0, 64, s));
-    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32);
+    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn);
     COL_LAUNCH_OK();
     if (capacity) {
         k_pairs_compact<<<dim3(512), dim3(256), 0, s>>>(pairs, hdr, blocks);
@@ -1117,6 +1203,14 @@ extern "C" int col_traverse_ghost_packets(void *stream, uint32_t *pairs, uint32_
 extern "C" {
 
 void col_debug_traverse(int variant) { g_traverse_variant = variant; }
+// diagnostics: the per-packet records of the profiling instances (variant bit 12), 4 words per packet: ticks of 10 ns
+// {phase 1, phase 2, loading the packet's own leaf records, start tick}; npackets <= 2^18
+int col_debug_walk_profile(uint32_t *out, uint32_t npackets) {
+    if (npackets > COL_PROF_PACKETS) return COL_EINVAL;
+    COL_HIP(hipDeviceSynchronize());
+    COL_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_prof), 16ull * npackets));
+    return COL_OK;
+}
 
 int col_bvh_build(void *stream, const uint32_t *codes, const uint32_t *ids, col_node *nodes, void *bounds,
                   uint32_t n, int coord_bytes) {
@@ -1177,7 +1271,7 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
     const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32);
-    if (coord_bytes != 4 || !off32 || !scratch || g_traverse_variant)
+    if (coord_bytes != 4 || !off32 || !scratch || (g_traverse_variant & ~(16384 | 32768)))
         return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
@@ -1273,9 +1367,14 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
         if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter, publish))) return rc;
         if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
     }
-    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes))) return rc;
+    // the traversal's packet counters (dynamic packet order, k_traverse): cleared by the tree build's last kernel
+    // (variant bit 15: from any size, so that the small parity cases of tests/ take this way too)
+    uint32_t *sched = (!chunked && (n >= COL_DYNAMIC_PACKETS_FROM || (g_traverse_variant & 32768))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr)) : nullptr;
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched))) return rc;
     if (chunked) return col_traverse_chunked(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr);
-    return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
+    if (n < 2) return COL_OK;
+    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched);
+    return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched);
 }
 
 }  // extern "C"

@@ -24,7 +24,8 @@ extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii
                              uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
                              uint32_t *zero_word, uint32_t *publish);
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
-                           const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes);
+                           const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes,
+                           uint32_t *zero8);      // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
 
 // col_collide's fused front end for inputs sorted with the 1024-pair tile (fewer launches, same bits):
 //  * col_minmax4_stage1: stage 1 of col_reduce(MINMAX, width 4) only; `parts` partial results of

@@ -388,8 +388,9 @@ constexpr u32 LIN = 32;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
-                                               const T *__restrict__ partial, Tabs tabs, u32 n, int lin) {
+                                               const T *__restrict__ partial, Tabs tabs, u32 n, int lin, u32 *__restrict__ zero8) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (zero8 && i < 8) zero8[i] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
     if (i + 1 >= n) return;
     const u32 j = other_end[i];
     const u32 first = min(i, j), last = max(i, j);
@@ -447,7 +448,7 @@ Layout layout(uint32_t n, int coord_bytes) {
 
 template <typename T>
 int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
-        col_node *nodes, T *bounds, char *scratch, u32 n) {
+        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
@@ -473,7 +474,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         COL_LAUNCH_OK();
         if (groups < 2) break;
     }
-    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n, lin);
+    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n, lin, zero8);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -489,22 +490,22 @@ size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, co
 
 // `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
 int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
-                const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
+                const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8) {
     if (n == 0) return COL_OK;
     if (n >= 0x80000000u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
         return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
-                          nodes, (float *)bounds, (char *)scratch, n);
+                          nodes, (float *)bounds, (char *)scratch, n, zero8);
     if (coord_bytes == 8)
         return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
-                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n);
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8);
     return COL_EINVAL;
 }
 
 int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
              col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
-    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes);
+    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr);
 }
 
 }  // extern "C"

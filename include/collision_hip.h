@@ -190,6 +190,7 @@ int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint3
 /* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
  * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
+int col_debug_walk_profile(uint32_t *out, uint32_t npackets);   /* diagnostics: see csrc/bvh.hip */
 void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off */
 void col_debug_leaf_blocks(float k);    /* leaf-block criterion of col_lbvh (process-wide): a node of <= 16 leaves is marked when it is at

@@ -29,3 +29,10 @@ for B in (0, 8, 16, 32, 64):
     np_ = (n + 63) // 64
     print("B=%2d: steps/packet %.1f descents %.1f leaf steps %.1f blocks %.1f block leaves %.1f" %
           (B, out[0] / np_, out[1] / np_, out[2] / np_, out[4] / np_, out[5] / np_))
+
+for B in (0, 16):
+    for K in (1, 2, 3, 4):
+        out = (C.c_uint64 * 8)()
+        lib.sim_walk_ctx(nodes.ctypes.data_as(C.c_void_p), bnds.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_int(B), C.c_int(K), out)
+        np_ = (n + 63) // 64
+        print("contexts %d B=%2d: rounds/packet %.1f fetches %.1f single rounds %.1f" % (K, B, out[0] / np_, out[1] / np_, out[2] / np_))

@@ -56,3 +56,64 @@ void sim_walk(const node_t *nodes, const float *bounds, uint32_t n, int B, uint6
     }
     free(skip); free(lo); free(cnt); free(stack);
 }
+
+/* K interleaved walk contexts per packet, in lockstep rounds (every active context fetches one record per round, the
+ * fetches of a round overlap).  A context walks a range [cur, term) of the skip chain; when it fetches a node whose
+ * skip link is not its terminator and another context is idle, it keeps the node's subtree and hands [skip, term) over.
+ * out[0] = rounds, out[1] = fetches, out[2] = rounds in which only one context fetched.  Leaf blocks (B) as in sim_walk:
+ * a block is tested inside the round of the context that met it. */
+void sim_walk_ctx(const node_t *nodes, const float *bounds, uint32_t n, int B, int K, uint64_t *out) {
+    const uint32_t nn = 2 * n - 1, leaf0 = n - 1, END = 0xFFFFFFFFu;
+    uint32_t *skip = malloc(4ull * nn), *lo = malloc(4ull * nn), *cnt = malloc(4ull * nn), *stack = malloc(4ull * nn);
+    int sp = 0;
+    skip[0] = END; stack[sp++] = 0;
+    while (sp) {
+        uint32_t x = stack[--sp];
+        if (x >= leaf0) continue;
+        uint32_t a = nodes[x].data[0], b = nodes[x].data[1];
+        skip[a] = b; skip[b] = skip[x];
+        stack[sp++] = a; stack[sp++] = b;
+    }
+    for (uint32_t x = 0; x < nn; x++) {
+        uint32_t y = x;
+        while (y < leaf0) y = nodes[y].data[0];
+        lo[x] = y - leaf0;
+        cnt[x] = (x >= leaf0 ? (x - leaf0) : nodes[x].right_edge) - lo[x] + 1;
+    }
+    memset(out, 0, 8 * 8);
+    const uint32_t npackets = (n + 63) / 64;
+    for (uint32_t p = 0; p < npackets; p++) {
+        const uint32_t q0 = p * 64, q1 = (q0 + 64 < n ? q0 + 64 : n);
+        uint32_t cur[8], term[8]; int act[8];
+        for (int k = 0; k < K; k++) act[k] = 0;
+        cur[0] = skip[leaf0 + q1 - 1]; term[0] = END; act[0] = cur[0] != END;
+        for (;;) {
+            int nact = 0;
+            for (int k = 0; k < K; k++) nact += act[k];
+            if (!nact) break;
+            out[0]++; out[1] += nact; if (nact == 1) out[2]++;
+            int was[8];
+            for (int k = 0; k < K; k++) was[k] = act[k];
+            for (int k = 0; k < K; k++) {
+                if (!was[k]) continue;
+                const uint32_t idx = cur[k];
+                const float *r = bounds + 8ull * idx;
+                int any = 0;
+                for (uint32_t q = q0; q < q1 && !any; q++) {
+                    const float *b = bounds + 8ull * (leaf0 + q);
+                    any = b[4] > r[0] && b[0] < r[4] && b[5] > r[1] && b[1] < r[5] && b[6] > r[2] && b[2] < r[6];
+                }
+                uint32_t next = skip[idx];
+                const int descend = any && idx < leaf0 && !(B > 0 && cnt[idx] <= (uint32_t)B);
+                if (descend && next != term[k]) {            /* hand the continuation over to an idle context */
+                    for (int j = 0; j < K; j++)
+                        if (!act[j]) { act[j] = 1; cur[j] = next; term[j] = term[k]; term[k] = next; break; }
+                }
+                if (descend) next = nodes[idx].data[0];
+                cur[k] = next;
+                if (next == term[k]) act[k] = 0;
+            }
+        }
+    }
+    free(skip); free(lo); free(cnt); free(stack);
+}

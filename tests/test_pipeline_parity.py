@@ -442,3 +442,44 @@ def test_dense_scenes_switch_to_chunked_allocation_on_their_own(hip_env, oracle)
         assert int(hip.read_buffer(cq, nb, np.uint32, 1)[0]) == ref["count"]
         assert_same_pair_set(hip.read_buffer(cq, pb, np.uint32, (ref["count"], 2)), ref["pairs"])
     assert [p & 2 for p in plans] == [0, 0, 2, 2], plans          # call k's count is published by call k + 1, seen by call k + 2
+
+
+@pytest.mark.parametrize("scene", ["uniform_f32", "uniform_f64", "clustered", "ragged_last_packet", "tiny_capacity",
+                                   "back_to_back"])
+def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene):
+    """From 1.5 M spheres on (and always with chunked allocation) the traversal's workgroups draw their packets from
+    per-XCD counters instead of a fixed stride (csrc/bvh.hip: dynamic packet order; the counters are cleared by the tree
+    build's last kernel).  col_debug_traverse bit 15 makes every size take that way: same arrays, same pair set, also
+    when the same collider runs again (the counters must be cleared every time) and with a list that is too small."""
+    from collision_amd._lib import cdll
+    lib = cdll()
+    lib.col_debug_traverse(32768)
+    try:
+        if scene == "uniform_f32":
+            coords, radii = uniform_scene(300000, 0.004, "float32")
+            check_against_oracle(oracle, hip_env, coords, radii, group_size=256)
+        elif scene == "uniform_f64":
+            coords, radii = uniform_scene(70001, 0.006, "float64")
+            check_against_oracle(oracle, hip_env, coords, radii, group_size=128)
+        elif scene == "clustered":
+            coords, radii = clustered_scene(120000, 0.01, 0.002, "float32")
+            check_against_oracle(oracle, hip_env, coords, radii, traverse_plan="exact")
+        elif scene == "ragged_last_packet":
+            coords, radii = uniform_scene(8192 + 129, 0.02, "float32")          # 131 packets: the 8 XCD ranges are 16 or 17 packets
+            check_against_oracle(oracle, hip_env, coords, radii)
+        elif scene == "tiny_capacity":
+            coords, radii = clustered_scene(50000, 0.01, 0.002, "float32")
+            _, _, count, pairs = check_against_oracle(oracle, hip_env, coords, radii, capacity=1000, traverse_plan="exact")
+            ref = oracle.collide(oracle.pad4(coords), radii, capacity=count)
+            assert len(pairs) == 1000 == len(pair_set(pairs)) and pair_set(pairs) <= pair_set(ref["pairs"])
+        else:
+            ctx, cq = hip_env
+            coords, radii = uniform_scene(200000, 0.004, "float32")
+            ref = oracle.collide(oracle.pad4(coords), radii, capacity=1 << 20)
+            collider = Collider(ctx, len(coords), 8, 256)
+            for _ in range(3):
+                count, pairs = run_collider(ctx, cq, collider, coords, radii, 1 << 20)
+                assert count == ref["count"]
+                assert_same_pair_set(pairs, ref["pairs"])
+    finally:
+        lib.col_debug_traverse(0)
