@@ -136,9 +136,10 @@ constexpr int HALO = 256;
 constexpr int WIN = C + 2 * HALO;
 // I: the type of a (possibly out-of-range) leaf position in the Karras search: int32_t below 2^30 leaves --
 // i +- 2 * range cannot overflow it, and 32-bit index arithmetic is half the vector instructions -- else int64_t
+typedef __attribute__((address_space(3))) const u32 LdsWord;
 template <typename I> struct Codes {
     const u32 *__restrict__ g;
-    const u32 *win;
+    LdsWord *win;              // (an LDS pointer by type: as a generic pointer the two sides of at() become ONE flat_load)
     I w0;
     u32 n;
     __device__ __forceinline__ u32 at(I j) const {
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     const u32 chunk = blockIdx.x;
     const u32 c0 = chunk * C;
     const u32 p = c0 + tid;
-    Codes<I> codes = {gcodes, s_codes, (I)c0 - HALO, n};
+    Codes<I> codes = {gcodes, (LdsWord *)s_codes, (I)c0 - HALO, n};
     for (int o = tid; o < WIN; o += C) {
         const I j = codes.w0 + o;
         s_codes[o] = (j >= 0 && j < (I)n) ? gcodes[j] : 0u;
