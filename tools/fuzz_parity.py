@@ -4,6 +4,7 @@ and value widths, key distributions) against NumPy's stable argsort.  Test infra
 oracle as the checker, like tests/.
 
     python tools/fuzz_parity.py [seconds] [seed] [logfile] [first]     (first: skip the iterations before it)
+COLLISION_FUZZ_TRAVERSE=<col_debug_traverse variant>, e.g. 32768: the dynamic packet order at every size.
 """
 import os
 import sys
@@ -29,6 +30,10 @@ def say(msg):
 
 
 rng = np.random.RandomState(seed)
+if os.environ.get("COLLISION_FUZZ_TRAVERSE"):
+    from collision_amd._lib import cdll
+    cdll().col_debug_traverse(int(os.environ["COLLISION_FUZZ_TRAVERSE"]))
+    say("col_debug_traverse(%s)" % os.environ["COLLISION_FUZZ_TRAVERSE"])
 oracle_mod.build()
 ctx = hip.Context()
 cq = hip.CommandQueue(ctx)
