@@ -110,6 +110,11 @@ _PROTOS = {
     "col_traverse_chunked_scratch_bytes": (C.c_size_t, []),
     "col_traverse_chunked": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                     C.c_void_p]),
+    "col_reduce_rtc_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "col_reduce_rtc_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "col_reduce_rtc_destroy": (C.c_int, [C.c_void_p]),
+    "col_reduce_rtc": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_walk_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),

@@ -109,6 +109,21 @@ int col_reduce(void *stream, const void *values, uint64_t n, int dtype, int widt
 int col_reduce_list(void *stream, const void *values, uint64_t n, int dtype, int width, int n_acc, const int *ops,
                     const double *inits, const int64_t *int_inits, void *scratch, void *out);
 
+/* ANY accumulator list, as the reference's template takes it (collision/reduce.py:9-22: every (initial value, binary
+ * function name) pair is rendered into reduce.cl and compiled at run time): `source` is a HIP rendering of
+ * reduce.cl:5-58 with two kernels, bounds1(values, n, group_accs) and bounds2(group_accs, output) -- the host side
+ * (collision_amd/reduce.py) writes it -- compiled with hiprtc (loaded on first use) for the current device.
+ * col_reduce_rtc launches it as reduce.py:62-76 does: bounds1 on ngroups x group_size work-items with acc_bytes of LDS
+ * per work-item, bounds2 on one group of ngroups work-items; so a function that is not associative meets its operands
+ * in the reference's order.  ngroups, group_size <= 1024 and acc_bytes * max(ngroups, group_size) <= 65536.
+ * partials: ngroups * acc_bytes bytes.  out: acc_bytes bytes, one row per accumulator (reduce.cl:55-58).
+ * log (may be NULL): the compiler's messages.  col_reduce_rtc_check compiles only (no device): for tests. */
+int col_reduce_rtc_check(const char *source, const char *arch, char *log, size_t log_cap);
+int col_reduce_rtc_create(const char *source, char *log, size_t log_cap, void **handle);
+int col_reduce_rtc_destroy(void *handle);
+int col_reduce_rtc(void *stream, void *handle, const void *values, uint64_t n, uint32_t ngroups, uint32_t group_size,
+                   uint32_t acc_bytes, void *partials, void *out);
+
 /* ---------------------------------------------------------------- morton
  * Replaces the `range` kernel, the padding fill and `calculateCodes`
  * (collision/collision.py:137-146,161-165; collision/collision.cl:8-40).

@@ -85,6 +85,87 @@ def bounds(values):
     return out
 
 
+def _int_info(dt):
+    info = np.iinfo(dt)
+    return int(info.min), int(info.max)
+
+
+def _cl_binary(name, dt):
+    """OpenCL's binary built-in `name` (or reduce.cl:3's ADD) on arrays of scalar dtype `dt`, as NumPy arithmetic in that
+    dtype -- the functions whose results NumPy can give exactly."""
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        table = {
+            "ADD": lambda a, b: (a + b).astype(dt), "MUL": lambda a, b: (a * b).astype(dt),
+            "min": lambda a, b: np.where(b < a, b, a), "max": lambda a, b: np.where(a < b, b, a),
+            "fmin": np.fmin, "fmax": np.fmax, "copysign": np.copysign,
+            "maxmag": lambda a, b: np.where(np.abs(a) > np.abs(b), a, np.where(np.abs(b) > np.abs(a), b, np.fmax(a, b))),
+            "minmag": lambda a, b: np.where(np.abs(a) < np.abs(b), a, np.where(np.abs(b) < np.abs(a), b, np.fmin(a, b))),
+            "fdim": lambda a, b: np.where(np.isnan(a) | np.isnan(b), np.nan, np.where(a > b, a - b, 0)).astype(dt),
+        }
+        return table[name]
+    lo, hi = _int_info(dt)
+    bits = 8 * dt.itemsize
+
+    def big(f):          # exact integer arithmetic on Python ints, wrapped / clipped back into dt
+        def g(a, b):
+            out = [f(int(x), int(y)) for x, y in zip(np.ravel(a), np.ravel(b))]
+            return np.array([((v - lo) % (1 << bits)) + lo for v in out], dtype=object).astype(dt).reshape(np.shape(a))
+        return g
+    table = {
+        "ADD": big(lambda x, y: x + y), "MUL": big(lambda x, y: x * y),
+        "min": lambda a, b: np.where(b < a, b, a), "max": lambda a, b: np.where(a < b, b, a),
+        "add_sat": big(lambda x, y: min(max(x + y, lo), hi)), "sub_sat": big(lambda x, y: min(max(x - y, lo), hi)),
+        "hadd": big(lambda x, y: (x + y) >> 1), "rhadd": big(lambda x, y: (x + y + 1) >> 1),
+        "abs_diff": big(lambda x, y: abs(x - y)), "mul_hi": big(lambda x, y: (x * y) >> bits),
+    }
+    return table[name]
+
+
+def reduce_list(values, accumulator, ngroups, group_size):
+    """reduce.cl:5-58 for ANY accumulator list [(initial value, function name), ...] on ngroups x group_size work-items
+    (reduce.py:62-76): every work-item folds values[gid], values[gid + G], ... into its accumulators in that order
+    (reduce.cl:13-17), a group folds its work-items' rows by the halving tree of reduce.cl:22-33 (row l + o into row l),
+    bounds2 folds the group rows the same way (reduce.cl:40-52).  Sizes that are not powers of two: every row is folded
+    (the tree starts at the next power of two; the reference's `o = size / 2` loop would drop rows).
+    values (n, width) -> (len(accumulator), width).  NumPy arithmetic in the value dtype: exact for the functions of
+    _cl_binary."""
+    values = np.ascontiguousarray(values)
+    if values.ndim == 1:
+        values = values.reshape(-1, 1)
+    dt, width, n = values.dtype, values.shape[1], len(values)
+    G = ngroups * group_size
+    out = np.empty((len(accumulator), width), dtype=dt)
+    consts = {"INFINITY": np.inf, "-INFINITY": -np.inf, "FLT_MAX": float(np.finfo(np.float32).max), "DBL_MAX": float(np.finfo(np.float64).max),
+              "SHRT_MAX": 32767, "SHRT_MIN": -32768, "INT_MAX": 2 ** 31 - 1, "INT_MIN": -2 ** 31, "UINT_MAX": 2 ** 32 - 1,
+              "LONG_MAX": 2 ** 63 - 1, "LONG_MIN": -2 ** 63, "ULONG_MAX": 2 ** 64 - 1, "UCHAR_MAX": 255, "USHRT_MAX": 65535}
+
+    def tree(rows):                                     # rows: (groups, size, width) -> (groups, width)
+        size = rows.shape[1]
+        top = 1
+        while top < size:
+            top <<= 1
+        o = top // 2
+        while o > 0:
+            m = min(o, size - o)                        # l < o and l + o < size
+            if m > 0:
+                rows[:, :m] = fn(rows[:, :m], rows[:, o:o + m])
+            o //= 2
+        return rows[:, 0]
+
+    with np.errstate(all="ignore"):
+        for k, (init, name) in enumerate(accumulator):
+            fn = _cl_binary(name, dt)
+            start = consts[str(init)] if str(init) in consts else (float(init) if dt.kind == "f" else int(str(init), 0))
+            acc = np.full((G, width), start, dtype=dt)
+            for i in range(0, n, G):
+                rows = values[i:i + G]
+                acc[:len(rows)] = fn(acc[:len(rows)], rows)
+            groups = tree(acc.reshape(ngroups, group_size, width).copy())
+            out[k] = tree(groups.reshape(1, ngroups, width).copy())[0]
+    return out
+
+
 def morton(coords4, rng):
     """collision.cl:22-40. coords4 (n,4), rng (2,4) -> uint32 codes."""
     coords4 = np.ascontiguousarray(coords4)

@@ -103,18 +103,73 @@ def test_generic_accumulator_lists(hip_env, value_dtype):
 
 
 def test_generic_accumulator_errors(hip_env):
-    from collision_amd.reduce import ReductionProgram
-    ctx, _ = hip_env
+    """A list the compiler cannot make sense of is a ValueError that carries its messages (the reference fails in
+    pyopencl's build the same way); so is a geometry whose accumulators do not fit a group's local memory."""
+    from collision_amd.reduce import ReductionProgram, Reducer
+    ctx, cq = hip_env
 
     class Bad(ReductionProgram):
-        accumulator = [("0", "atan2")]
+        accumulator = [("0", "no_such_function")]
 
-    class TooMany(ReductionProgram):
-        accumulator = [("0", "ADD")] * 5
+    with pytest.raises(ValueError, match="no_such_function"):
+        Bad(ctx, np.dtype("float32"))
 
-    for cls in (Bad, TooMany):
-        with pytest.raises(ValueError):
-            cls(ctx, np.dtype("float32"))
+    class Wide(ReductionProgram):
+        accumulator = [("0", "hypot")] * 40
+
+    class WideReducer(Reducer):
+        program_type = Wide
+
+    r = WideReducer(ctx, 8, 1024, np.dtype(("float64", 4)))                 # 40 x 4 x 8 bytes x 1024 work-items
+    with pytest.raises(ValueError, match="too large"):
+        r.reduce(cq, 10, upload(ctx, np.zeros((10, 4))), hip.Buffer(ctx, 40 * 32))
+
+
+RENDERED_LISTS = {
+    # float ADD on arbitrary floats: the sum depends on the order -- the reference's order is the contract
+    "float32": [("0", "ADD"), ("INFINITY", "fmin"), ("-INFINITY", "fmax"), ("1", "copysign"), ("0", "maxmag"),
+                ("INFINITY", "minmag"), ("0", "fdim")],
+    "float64": [("0", "ADD"), ("-INFINITY", "max"), ("INFINITY", "min"), ("0", "maxmag"), ("1", "copysign")],
+    "uint8": [("0", "add_sat"), ("0", "ADD"), ("0", "hadd"), ("255", "min"), ("0", "rhadd"), ("0", "abs_diff"), ("7", "mul_hi")],
+    "int16": [("SHRT_MAX", "min"), ("0", "add_sat"), ("0", "sub_sat"), ("-3", "mul_hi"), ("0", "abs_diff")],
+    "int64": [("LONG_MIN", "max"), ("0", "add_sat"), ("0x7fffffffffffffff", "min"), ("0", "rhadd"), ("0", "hadd")],
+    "uint32": [("0", "ADD"), ("0", "max"), ("UINT_MAX", "min"), ("0", "rhadd"), ("0", "sub_sat")],
+}
+
+
+@pytest.mark.parametrize("geometry", [(8, 64), (5, 48), (1, 1), (16, 256)], ids=str)
+@pytest.mark.parametrize("value_dtype", [np.dtype("float32"), np.dtype(("float64", 3)), np.dtype(("uint8", 4)), np.dtype("int16"),
+                                         np.dtype(("int64", 2)), np.dtype("uint32")], ids=str)
+def test_rendered_accumulator_lists(hip_env, oracle, value_dtype, geometry):
+    """reduce.py:9-22: ANY accumulator list.  What the compiled-in kernels and the table-driven reducer do not cover is
+    rendered into HIP with the structure of reduce.cl and compiled at run time (collision_amd/reduce.py render_source,
+    csrc/rtc_reduce.hip); it runs on the caller's ngroups x group_size work-items, so every function -- also one that is
+    not associative, like a float ADD on arbitrary values -- gives the bits of the reference's order of operations
+    (oracle.reduce_list restates it).  Geometries that are not powers of two fold every partial."""
+    from collision_amd.reduce import ReductionProgram, Reducer
+    ctx, cq = hip_env
+    vd = _device_dtype(value_dtype)
+    acc = RENDERED_LISTS[vd.base.name]
+    program = type("P", (ReductionProgram,), {"accumulator": acc})
+    reducer = type("R", (Reducer,), {"program_type": program})
+    assert program(ctx, value_dtype).rtc is not None                         # not one of the table's lists
+    ngroups, group_size = geometry
+    rs = np.random.RandomState(5)
+    for n in (0, 1, 777, 100003):
+        shape = (n,) + (vd.shape or (1,))
+        if vd.base.kind == "f":
+            values = ((rs.random_sample(shape) - 0.5) * 8).astype(vd.base)
+        else:
+            info = np.iinfo(vd.base)
+            values = rs.randint(max(info.min, -(1 << 40)), min(info.max, 1 << 40), size=shape, dtype=np.int64).astype(vd.base)
+        out_buf = hip.Buffer(ctx, len(acc) * dtype_sizeof(value_dtype))
+        src = upload(ctx, values) if n else hip.Buffer(ctx, 16)
+        e = reducer(ctx, ngroups, group_size, value_dtype).reduce(cq, n, src, out_buf)
+        out = download(cq, out_buf, vd.base, (len(acc),) + (vd.shape or (1,)), wait_for=[e])
+        want = oracle.reduce_list(values.reshape(n, shape[1]), acc, ngroups, group_size)
+        if value_dtype.shape == (3,):                                        # the fourth lane of a 3-vector is padding
+            out, want = out[:, :3], want[:, :3]
+        np.testing.assert_array_equal(out.view(np.uint8), want.view(np.uint8), err_msg="n=%d" % n)
 
 
 def test_integer_initial_values_are_exact(hip_env):

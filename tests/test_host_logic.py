@@ -226,3 +226,36 @@ def test_scratch_sizes_are_monotone_in_n():
     # the two cases of the round-1 advisor note
     assert call.col_collide_scratch_bytes(1048064, 1048064, 4) <= call.col_collide_scratch_bytes(1049088, 1049088, 4)
     assert call.col_collide_scratch_bytes(16776704, 16776704, 4) <= call.col_collide_scratch_bytes(16777728, 16777728, 4)
+
+
+def test_rendered_reductions_compile_without_a_device():
+    """Any accumulator list (reduce.py:9-22) that is not compiled in is rendered into HIP and compiled by hiprtc at run
+    time; the rendering and the compile step need no GPU (col_reduce_rtc_check).  Also: what the compiler says about
+    a function it does not know reaches the caller."""
+    import ctypes as C
+    from collision_amd._lib import cdll
+    from collision_amd.reduce import render_source
+    from tests.test_bounds_py import RENDERED_LISTS
+    lib = cdll()
+    log = C.create_string_buffer(1 << 14)
+    for name, acc in RENDERED_LISTS.items():
+        for shape in ((), (3,)):
+            src = render_source(np.dtype((name, shape)) if shape else np.dtype(name), acc)
+            assert lib.col_reduce_rtc_check(src.encode(), b"gfx950", log, len(log)) == 0, log.value.decode()
+    src = render_source(np.dtype("float32"), [("0", "no_such_function")])
+    assert lib.col_reduce_rtc_check(src.encode(), b"gfx950", log, len(log)) != 0
+    assert b"no_such_function" in log.value
+
+
+def test_generic_reduction_restatement_agrees_with_numpy(oracle):
+    """oracle.reduce_list (reduce.cl:5-58 for any accumulator list, the checker of the rendered reductions) against
+    plain NumPy where the order of operations does not matter."""
+    rs = np.random.RandomState(2)
+    v = rs.randint(-1000, 1000, size=(5000, 3)).astype(np.int64)
+    for geometry in ((8, 64), (5, 48), (1, 1)):
+        out = oracle.reduce_list(v, [("0", "ADD"), ("LONG_MAX", "min"), ("LONG_MIN", "max")], *geometry)
+        np.testing.assert_array_equal(out, np.stack([v.sum(0), v.min(0), v.max(0)]))
+    f = rs.random_sample((4096, 2)).astype(np.float32)
+    out = oracle.reduce_list(f, [("INFINITY", "fmin"), ("-INFINITY", "fmax"), ("0", "ADD")], 8, 64)
+    np.testing.assert_array_equal(out[:2], np.stack([f.min(0), f.max(0)]))
+    np.testing.assert_allclose(out[2], f.sum(0, dtype=np.float64), rtol=1e-5)
