@@ -236,7 +236,17 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     __shared__ ChunkLds<T> lds;
     __shared__ u32 s_codes[WIN];
     const int tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
-    const u32 chunk = blockIdx.x;
+    // XCD-aware order: blockIdx % 8 is the XCD (each with its own L2).  Every XCD builds one contiguous run of chunks -- the
+    // same eighth of the sorted leaves whose packets it walks in k_traverse, and neighbouring chunks read overlapping code
+    // windows.  Same bits; whole path, interleaved A/B of two builds on one box: 1 M uniform 0.1706-0.1736 against
+    // 0.1744-0.1757 ms, 2 M 0.293-0.296 against 0.298-0.301, 16 M and config 3 unchanged; a clustered scene at 2 M loses
+    // 2.5 % (the deep chunks of a cluster all go to one XCD; strips of 16 chunks going round the XCDs avoid that and
+    // gain 0.4 % instead of 1.5 %: not taken).  col_debug_lbvh bit 5 restores chunk = blockIdx.
+    u32 chunk = blockIdx.x;
+    if (!(dbg & 32)) {
+        const u32 q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x & 7u;
+        chunk = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+    }
     const u32 c0 = chunk * C;
     const u32 p = c0 + tid;
     Codes<I> codes = {gcodes, (LdsWord *)s_codes, (I)c0 - HALO, n};

@@ -18,7 +18,8 @@ def run():
     call.col_lbvh(cq.stream, col._codes_bufs[1].ptr, col._ids_bufs[1].ptr, cb.ptr, rb.ptr, col._nodes_buf.ptr,
                   col._bounds_buf.ptr, scratch.ptr, n, 4)
 for mode, what in ((0, "full"), (1, "no gather (coords[p])"), (2, "no parent stores"), (4, "leaves only"),
-                   (8, "no box wait / record store"), (3, "no gather, no parent"), (0, "full")):
+                   (8, "no box wait / record store"), (3, "no gather, no parent"), (32, "chunk = blockIdx (plain order)"), (0, "full"),
+                   (32, "chunk = blockIdx (plain order)")):
     cdll().col_debug_lbvh(mode)
     run(); cq.finish()
     print("mode %d %-28s %.4f ms" % (mode, what, bench.time_events(hip, cq, run, 20)))
