@@ -454,7 +454,8 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                     // (the XCD's packet range and counter are worked out here, once per batch, rather than kept in registers:
                     // the kernel has none to spare)
                     const u32 x = blockIdx.x & 7u, ng = (npackets + TW - 1) / TW;
-                    const u32 p_lo = (u32)(((u64)ng * x) >> 3) * TW, p_hi = min((u32)(((u64)ng * (x + 1)) >> 3) * (u32)TW, npackets);
+                    const u32 p_lo = (u32)(((u64)ng * x) >> 3) * TW, p_end = min((u32)(((u64)ng * (x + 1)) >> 3) * (u32)TW, npackets);
+                    const u32 p_hi = (mode & 512) ? p_end + (p_end - min(p_lo, p_end)) : p_end;      // split units: walks, then phase 1s
                     u32 *sched_ctr = ((mode & 32) ? reinterpret_cast<ChunkHdr *>(stats)->pad : reinterpret_cast<u32 *>(stats)) + x;
                     u32 nb = 0;
                     if (lane == 0) nb = atomicAdd(sched_ctr, (u32)TW);
@@ -477,6 +478,17 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
             packet = group * TW + w;
             group += g_step;
             if (packet >= npackets) continue;
+        }
+        // SPLIT UNITS (mode bit 9, with the dynamic order): a packet is two units of work -- its walk (phase 2), drawn first,
+        // and its phase 1, drawn when every walk of the XCD has been handed out: the short phase-1 units fill the wave slots
+        // that the last long walks leave idle
+        bool only1 = false, only2 = false;
+        if (dyn && (mode & 512)) {
+            const u32 x = blockIdx.x & 7u, ng = (npackets + TW - 1) / TW;
+            const u32 p_lo = (u32)(((u64)ng * x) >> 3) * TW, p_end = min((u32)(((u64)ng * (x + 1)) >> 3) * (u32)TW, npackets);
+            only1 = packet >= p_end;
+            only2 = !only1;
+            if (only1) packet -= p_end - p_lo;
         }
         const u32 q0 = packet * 64, q = q0 + lane;
         u64 prof_t0 = 0, prof_t1 = 0, prof_t2 = 0;
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // per axis inside the packet's union box (lo rounded down, hi rounded up: a real overlap
         // always survives).  The three axes sit in 10-bit fields of one word, and "a >= b in every
         // field" is one subtraction: bit 8 of each field of (a + 0x100) - b.
-        if (!GHOST && !(mode & 1)) {
+        if (!GHOST && !(mode & 1) && !only2) {
             // the packet's union box: six wave reductions on the DPP network (6 steps + one v_readlane each,
             // no LDS) instead of six xor-shuffle butterflies through ds_bpermute (36 LDS round trips)
             T ul[3], uh[3];
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // are the hits) instead of producing six masks to AND, and runs of misses -- more than half of all steps --
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
-        if (mode & 2) idx = END;
+        if ((mode & 2) || only1) idx = END;
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         }
         if constexpr (PROF) {
             const u64 prof_t3 = wall_clock64();
-            if (lane == 0 && packet < COL_PROF_PACKETS)
+            if (lane == 0 && packet < COL_PROF_PACKETS && !only1)
                 g_walk_prof[packet] = make_uint4((u32)(prof_t2 - prof_t1), (u32)(prof_t3 - prof_t2), (u32)(prof_t1 - prof_t0), (u32)prof_t0);
         }
     }
@@ -987,9 +999,13 @@ __global__ __launch_bounds__(TT) void k_traverse_lane(u32 *__restrict__ pairs, u
 }
 
 int g_traverse_variant = 0;       // diagnostics switch, see col_debug_traverse
-// from this many spheres on col_collide's traversal takes its packets in dynamic order (below it a wave has two packets
-// at most and the order changes nothing: 1 M 0.061 against 0.061 ms, 2 M 0.098 against 0.107, 16 M 0.74 against 0.90)
-#define COL_DYNAMIC_PACKETS_FROM 1500000u
+// from this many spheres on col_collide's traversal takes its work in dynamic order (k_traverse), and up to
+// COL_SPLIT_UNITS_UPTO a packet is two units (its walk, then its phase 1).  Whole path, one box, static / dynamic / dynamic
+// with split units (tools/dyn_ab.py): 0.5 M 0.119 / 0.123 / 0.119 ms, 1 M 0.171-0.177 / 0.172-0.174 / 0.168-0.169,
+// 2 M 0.302-0.312 / 0.292-0.294 / 0.291-0.292, 4 M 0.624-0.631 / 0.590 / 0.604-0.606, 16 M 2.44 / 2.27 / 2.39; config 3
+// (chunked allocation) 0.5 M 0.311 / 0.314 / 0.297, 1 M 0.602-0.609 / 0.585-0.589 / 0.558-0.566, 2 M 1.47 / 1.39 / 1.34
+#define COL_DYNAMIC_PACKETS_FROM 400000u
+#define COL_SPLIT_UNITS_UPTO 3000000u
 
 template <typename T>
 int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
@@ -1029,6 +1045,7 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     }
     if (sched && !st && !(g_traverse_variant & (16384 | 1 | 2 | 4 | 128 | 1024))) {      // (the other walks are A/B material)
         mode |= 256;
+        if ((n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072)) mode |= 512;      // split units
         if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
         else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
         else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
@@ -1149,7 +1166,8 @@ template <typename T>
 int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                             uint32_t n, void *scratch) {
     // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
-    const int dyn = (g_traverse_variant & 16384) ? 0 : 256;
+    const bool split = (n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072);
+    const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256);
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;
@@ -1271,7 +1289,7 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
     const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32);
-    if (coord_bytes != 4 || !off32 || !scratch || (g_traverse_variant & ~(16384 | 32768)))
+    if (coord_bytes != 4 || !off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
         return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;

@@ -17,7 +17,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000]:
         nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
         col = Collider(ctx, n, 64, 256)
         ref = None
-        for variant in (16384, 0, 16384, 0):
+        for variant in (16384, 131072, 0, 16384, 131072, 0):
             cdll().col_debug_traverse(variant)
             def step():
                 col.get_collisions(cq, cb, rb, nb, pb, cap)
@@ -28,6 +28,6 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000]:
             if ref is None: ref = pairs
             same = pairs.shape == ref.shape and bool((pairs == ref).all())
             ms = bench.time_events(hip, cq, step, 20)
-            print("n %9d %-8s %s: %.4f ms, pairs %d, same set: %s" % (n, name, "static " if variant else "dynamic", ms, cnt, same), flush=True)
+            print("n %9d %-8s %s: %.4f ms, pairs %d, same set: %s" % (n, name, {16384: "static ", 131072: "dynamic", 0: "dyn+split"}[variant], ms, cnt, same), flush=True)
         cdll().col_debug_traverse(0)
         del cb, rb, nb, pb, col
