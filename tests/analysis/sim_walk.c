@@ -117,3 +117,56 @@ void sim_walk_ctx(const node_t *nodes, const float *bounds, uint32_t n, int B, i
     }
     free(skip); free(lo); free(cnt); free(stack);
 }
+
+/* How would a packet's walk split in two at the j-th node of its top-level chain (the chain skip(last leaf), skip(that), ...)?
+ * out[j][0] = steps spent in the first j top-level subtrees, out[j][1] = steps in the rest, summed over the packets;
+ * out[j][2] / out[j][3] = the maximum of either part over the packets.  j = 1 .. 15. */
+void sim_walk_split(const node_t *nodes, const float *bounds, uint32_t n, uint64_t (*out)[4], uint32_t *per_packet /* [npackets][16]: steps by top-level subtree */) {
+    const uint32_t nn = 2 * n - 1, leaf0 = n - 1, END = 0xFFFFFFFFu;
+    uint32_t *skip = malloc(4ull * nn), *stack = malloc(4ull * nn);
+    int sp = 0;
+    skip[0] = END; stack[sp++] = 0;
+    while (sp) {
+        uint32_t x = stack[--sp];
+        if (x >= leaf0) continue;
+        uint32_t a = nodes[x].data[0], b = nodes[x].data[1];
+        skip[a] = b; skip[b] = skip[x];
+        stack[sp++] = a; stack[sp++] = b;
+    }
+    const uint32_t npackets = (n + 63) / 64;
+    memset(out, 0, 16 * 4 * 8);
+    for (uint32_t p = 0; p < npackets; p++) {
+        const uint32_t q0 = p * 64, q1 = (q0 + 64 < n ? q0 + 64 : n);
+        uint32_t top = skip[leaf0 + q1 - 1];
+        uint32_t steps[64]; int k = 0;
+        memset(steps, 0, sizeof(steps));
+        while (top != END) {
+            const uint32_t term = skip[top];
+            uint32_t idx = top, cnt = 0;
+            while (idx != term) {
+                const float *r = bounds + 8ull * idx;
+                int any = 0;
+                for (uint32_t q = q0; q < q1 && !any; q++) {
+                    const float *b = bounds + 8ull * (leaf0 + q);
+                    any = b[4] > r[0] && b[0] < r[4] && b[5] > r[1] && b[1] < r[5] && b[6] > r[2] && b[2] < r[6];
+                }
+                cnt++;
+                idx = (any && idx < leaf0) ? nodes[idx].data[0] : skip[idx];
+            }
+            if (k < 64) steps[k] = cnt;
+            k++;
+            top = term;
+        }
+        uint32_t total = 0;
+        for (int i = 0; i < 64; i++) total += steps[i];
+        uint32_t pre = 0;
+        for (int j = 1; j < 16; j++) {
+            pre += steps[j - 1];
+            out[j][0] += pre; out[j][1] += total - pre;
+            if (pre > out[j][2]) out[j][2] = pre;
+            if (total - pre > out[j][3]) out[j][3] = total - pre;
+        }
+        if (per_packet) for (int i = 0; i < 16; i++) per_packet[16ull * p + i] = i < 15 ? steps[i] : total;
+    }
+    free(skip); free(stack);
+}
