@@ -21,7 +21,9 @@
 //   k_group   (1-2 tiny launches) sparse tables over chunk totals, 256 chunks per group,
 //             then over group totals, ...
 //   k_cross   the ~1-2 % of nodes that cross chunks: partial[first] U partial[last] U
-//             O(1) table look-ups for the whole chunks in between.
+//             O(1) table look-ups for the whole chunks in between.  k_chunk lists them per chunk (CROSS_CAP words),
+//             k_cross runs one thread per list slot (round 3: 76 -> 43 us at 16 M spheres; a thread per NODE left
+//             one or two busy lanes per wave).
 //
 // partial[] is indexed by NODE index: a crossing node that runs forward from `first` owns
 // partial[first]; the far end `last` of that node is the index of the backward crossing node
@@ -187,7 +189,12 @@ template <typename T> struct ChunkLds {
     T node[6][C];
     u32 ready[C];
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
+    u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
 };
+// The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
+// a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
+// goes through all its nodes instead.
+constexpr u32 CROSS_CAP = 16, CROSS_DENSE = 0xFFFFFFFEu;
 template <typename T> __device__ __forceinline__ Box<T> soa_get(const T (&a)[6][C], int pos) {
     Box<T> b;
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
-                                             u32 *__restrict__ other_end, T *__restrict__ partial,
+                                             u32 *__restrict__ other_end, T *__restrict__ partial, u32 *__restrict__ cross,
                                              T *__restrict__ tab1, u32 n, T block_k, typename ChunkDiag<DIAG>::T diag) {
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     typedef typename BT<T>::V4 V4;
@@ -255,6 +262,8 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         s_codes[o] = (j >= 0 && j < (I)n) ? gcodes[j] : 0u;
     }
     lds.ready[tid] = 0;
+    if (tid < (int)CROSS_CAP) cross[(uint64_t)chunk * CROSS_CAP + tid] = END;       // (complete before the barrier below: the fence of __syncthreads)
+    if (tid == 0) lds.ncross = 0;
     const u32 leaf_start = n - 1;
     const bool valid = p < n;
 
@@ -372,6 +381,8 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         links_store(bounds, (uint64_t)i, skip, child_a);
         // this chunk's half of the range: suffix from i (forward) or prefix up to i (backward)
         box_store(partial, i, dir > 0 ? suf : pre);
+        const u32 slot = atomicAdd(&lds.ncross, 1u);
+        cross[(uint64_t)chunk * CROSS_CAP + (slot < CROSS_CAP - 1 ? slot : CROSS_CAP - 1)] = slot < CROSS_CAP - 1 ? i : CROSS_DENSE;
     }
 }
 
@@ -398,11 +409,8 @@ struct Tabs { void *t[3]; };
 constexpr u32 LIN = 32;
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
-                                               const T *__restrict__ partial, Tabs tabs, u32 n, int lin, u32 *__restrict__ zero8) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (zero8 && i < 8) zero8[i] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
-    if (i + 1 >= n) return;
+__device__ __forceinline__ void cross_node(T *__restrict__ bounds, const u32 *__restrict__ other_end, const T *__restrict__ partial,
+                                           const Tabs &tabs, u32 i, int lin) {
     const u32 j = other_end[i];
     const u32 first = min(i, j), last = max(i, j);
     int64_t a = first / C, b = last / C;
@@ -431,12 +439,33 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
     row[4] = box.hi[0]; row[5] = box.hi[1]; row[6] = box.hi[2];
 }
 
+// One thread per (chunk, list slot): CROSS_CAP threads per chunk instead of one per node -- a wave of the per-node version
+// had one or two crossing nodes among its 64 and ran their table look-ups at that utilisation (76 us at 16 M spheres).
+template <typename T>
+__global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
+                                               const T *__restrict__ partial, const u32 *__restrict__ cross, Tabs tabs, u32 n,
+                                               u32 nchunks, int lin, u32 *__restrict__ zero8) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (zero8 && t < 8) zero8[t] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
+    const u32 chunk = t / CROSS_CAP, slot = t % CROSS_CAP;
+    if (chunk >= nchunks) return;
+    if (cross[(uint64_t)chunk * CROSS_CAP + CROSS_CAP - 1] == CROSS_DENSE) {
+        for (u32 k = slot; k < (u32)C; k += CROSS_CAP) {
+            const u32 i = chunk * C + k;
+            if (i + 1 < n) cross_node(bounds, other_end, partial, tabs, i, lin);
+        }
+        return;
+    }
+    const u32 i = cross[(uint64_t)chunk * CROSS_CAP + slot];
+    if (i != END) cross_node(bounds, other_end, partial, tabs, i, lin);
+}
+
 int g_dbg = 0;         // process-wide diagnostics switch (col_debug_lbvh); see include/collision_hip.h
 float g_block_k = 3.0f;   // leaf-block density criterion (col_debug_leaf_blocks): node width <= k x leaf width; 0 = no marks
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t other_end, partial, tab[3], total;
+    size_t other_end, partial, cross, tab[3], total;
     u32 count[3];    // level-0 entries of each table: chunks, groups, groups of groups
 };
 
@@ -447,6 +476,7 @@ Layout layout(uint32_t n, int coord_bytes) {
     L.other_end = off; off += align256((size_t)n * 4);
     L.partial = off;   off += align256((size_t)n * entry);
     u32 cnt = (u32)col_ceil_div(n, C);
+    L.cross = off;     off += align256((size_t)cnt * CROSS_CAP * 4);
     for (int h = 0; h < 3; h++) {
         L.count[h] = cnt;
         const size_t groups = col_ceil_div(cnt, C);
@@ -463,17 +493,18 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
+    u32 *cross = (u32 *)(scratch + L.cross);
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
     if (g_dbg)
-        k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+        k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg});
     else if (n < (1u << 30))
-        k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+        k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     else
-        k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial,
+        k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     COL_LAUNCH_OK();
     if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
@@ -485,7 +516,8 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         COL_LAUNCH_OK();
         if (groups < 2) break;
     }
-    k_cross<T><<<dim3((unsigned)col_ceil_div(n - 1, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, tabs, n, lin, zero8);
+    k_cross<T><<<dim3((unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin,
+                                                                                                     zero8);
     COL_LAUNCH_OK();
     return COL_OK;
 }
