@@ -507,7 +507,10 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     COL_LAUNCH_OK();
-    if (nchunks < 2) return COL_OK;     // every node lives inside the single chunk
+    if (nchunks < 2) {                  // every node lives inside the single chunk: no k_cross, so clear the packet counters here
+        if (zero8) COL_HIP(hipMemsetAsync(zero8, 0, 8 * sizeof(u32), s));
+        return COL_OK;
+    }
     int lin = -1;
     for (int h = 0; h < 3; h++) {
         if (h > 0 && L.count[h] <= LIN) { lin = h; break; }      // k_cross scans this level's few entries itself

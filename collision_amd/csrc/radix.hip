@@ -280,7 +280,16 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     const bool norank = DIAG && (dbg & 65536);
     // rank inside (wave, digit): wave-private counters, program order keeps them consistent
     u32 pos[IT];
-    if (!norank) {
+    // (diagnostics, mode 1 << 21: the rank from ONE returning LDS atomic per item instead of match-any + counter.  Stable
+    // only if the LDS resolves lanes that hit the same address in lane order -- not an architectural promise, so an
+    // experiment: tools/radix_atomrank_ab.py compares its output with the production pass.)
+    const bool atomrank = DIAG && sizeof(CNT) == 4 && (dbg & (1 << 21));
+    if (atomrank) {
+        if constexpr (sizeof(CNT) == 4) {
+#pragma unroll
+            for (int k = 0; k < IT; k++) pos[k] = atomicAdd(reinterpret_cast<u32 *>(&s_cnt[w][digit_of(key[k], shift)]), 1u);
+        }
+    } else if (!norank) {
 #pragma unroll
     for (int k = 0; k < IT; k++) {
         const u32 d = digit_of(key[k], shift);
