@@ -1363,8 +1363,8 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
     uint32_t *publish = oversize ? oversize + 2 : nullptr;      // the previous call's pair count, for the caller's next choice
     int rc;
     const uint32_t tile = col_radix_tile(padded, 4, 4);
-    if (tile == 1024 || tile == 4096) {
-        // Up to 16 Mi spheres the front end is fused: the Morton kernel folds the bounds partials itself and
+    if (tile == 1024 || tile == 4096 || tile == 8192) {
+        // The front end is fused (every tile class of a (u32, u32) sort): the Morton kernel folds the bounds partials itself and
         // counts the digits of the sort's first pass (the histogram sits at the start of the sort scratch): two
         // launches less.  The MSD plan (one global pass + an LDS finish per bucket) applies up to COL_MSD_MAX_N.
         const bool msd = sort_plan == COL_SORT_MSD && padded <= COL_MSD_MAX_N;

@@ -218,6 +218,62 @@ template <typename T> __device__ __forceinline__ Box<T> box_shfl_down(const Box<
     return r;
 }
 
+// Inclusive prefix (lanes 0..l) and suffix (lanes l..63) unions of a wave's f32 boxes on the DPP network: per value one
+// v_min / v_max_f32_dpp per step (row_shr 1, 2, 4, 8 inside the rows of 16 -- a lane the shift does not reach keeps its
+// value --, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3), and for the suffix row_shl 1, 2, 4, 8
+// and three rounds "first lane of row 3 / 2 / 1 -> the rows below it" (v_readlane + a v_min / v_max under a narrowed EXEC:
+// there is no broadcast towards lower rows).  96 vector instructions and no LDS for the twelve scans instead of
+// 144 ds_bpermute + ~240 VALU.  The six values are interleaved, so dependent DPP steps are six instructions apart (two
+// wait states are needed after the VALU write of a DPP source, and after a VALU write of an SGPR that a VALU reads);
+// s_nop 1 at both ends because the compiler does not track these hazards across the asm boundary.  Needs a full wave.
+#define COL_SCAN6(ctrl)                                                                                                       \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t"        \
+    "v_max_f32_dpp %3, %3, %3 " ctrl "\n\tv_max_f32_dpp %4, %4, %4 " ctrl "\n\tv_max_f32_dpp %5, %5, %5 " ctrl "\n\t"
+#define COL_DOWN6(src_lane)                                                                                                   \
+    "v_readlane_b32 %6, %0, " src_lane "\n\tv_readlane_b32 %7, %1, " src_lane "\n\tv_readlane_b32 %8, %2, " src_lane "\n\t"   \
+    "v_readlane_b32 %9, %3, " src_lane "\n\tv_readlane_b32 %10, %4, " src_lane "\n\tv_readlane_b32 %11, %5, " src_lane "\n\t"
+#define COL_APPLY6                                                                                                            \
+    "v_min_f32 %0, %6, %0\n\tv_min_f32 %1, %7, %1\n\tv_min_f32 %2, %8, %2\n\t"                                               \
+    "v_max_f32 %3, %9, %3\n\tv_max_f32 %4, %10, %4\n\tv_max_f32 %5, %11, %5\n\t"
+__device__ __forceinline__ void wave_prefix_union(Box<float> &b) {
+    asm volatile("s_nop 1\n\t"
+                 COL_SCAN6("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 COL_SCAN6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]));
+}
+__device__ __forceinline__ void wave_suffix_union(Box<float> &b) {
+    u32 t0, t1, t2, t3, t4, t5;
+    u64 save;
+    asm volatile("s_nop 1\n\t"
+                 COL_SCAN6("row_shl:1 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shl:2 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shl:4 row_mask:0xf bank_mask:0xf")
+                 COL_SCAN6("row_shl:8 row_mask:0xf bank_mask:0xf")
+                 "s_mov_b64 %12, exec\n\t"
+                 "s_nop 1\n\t"
+                 COL_DOWN6("48")                                   // row 3's total -> rows 0..2
+                 "s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, 0xffff\n\t"
+                 COL_APPLY6
+                 COL_DOWN6("32")                                   // rows 2..3 -> rows 0..1
+                 "s_mov_b32 exec_hi, 0\n\t"
+                 COL_APPLY6
+                 COL_DOWN6("16")                                   // rows 1..3 -> row 0
+                 "s_mov_b32 exec_lo, 0xffff\n\t"
+                 COL_APPLY6
+                 "s_mov_b64 exec, %12\n\t"
+                 "s_nop 1"
+                 : "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]),
+                   "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(save));
+}
+#undef COL_SCAN6
+#undef COL_DOWN6
+#undef COL_APPLY6
+
 // node records without the `parent` word, which the parent's thread writes (collision.cl:119-120)
 struct __attribute__((packed, aligned(4))) LeafTail { u32 right_edge, id; };
 struct __attribute__((packed, aligned(4))) InnerTail { u32 right_edge, child_a, child_b; };
@@ -231,7 +287,7 @@ template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
 __device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
 __device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
 
-template <typename T, bool DIAG, typename I>
+template <typename T, bool DIAG, typename I, bool DPP_SCAN = false>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
@@ -293,11 +349,16 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
 
     // inclusive prefix / suffix unions over the chunk (wave shuffles, then the 4 wave totals)
     Box<T> pre = leaf, suf = leaf;
+    if constexpr (DPP_SCAN && sizeof(T) == 4) {          // (every lane of the block is still here: full waves)
+        wave_prefix_union(pre);
+        wave_suffix_union(suf);
+    } else {
 #pragma unroll
-    for (int o = 1; o < COL_WAVE; o <<= 1) {
-        const Box<T> up = box_shfl_up(pre, o), dn = box_shfl_down(suf, o);
-        if (lane >= o) box_merge(pre, up);
-        if (lane + o < COL_WAVE) box_merge(suf, dn);
+        for (int o = 1; o < COL_WAVE; o <<= 1) {
+            const Box<T> up = box_shfl_up(pre, o), dn = box_shfl_down(suf, o);
+            if (lane >= o) box_merge(pre, up);
+            if (lane + o < COL_WAVE) box_merge(suf, dn);
+        }
     }
     if (lane == COL_WAVE - 1) { for (int k = 0; k < 3; k++) { lds.wave_tot[0][w][k] = pre.lo[k]; lds.wave_tot[0][w][3 + k] = pre.hi[k]; } }
     if (lane == 0) { for (int k = 0; k < 3; k++) { lds.wave_tot[1][w][k] = suf.lo[k]; lds.wave_tot[1][w][3 + k] = suf.hi[k]; } }
@@ -497,9 +558,13 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
-    if (g_dbg)
+    // mode bit 10 (1024) alone is not a diagnostics mode: it selects the production instance with the shuffle scans (A/B)
+    if (g_dbg & ~1024)
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg});
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg & ~1024});
+    else if (n < (1u << 30) && sizeof(T) == 4 && !(g_dbg & 1024))
+        k_chunk<T, false, int32_t, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
+                                                                           (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     else if (n < (1u << 30))
         k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});

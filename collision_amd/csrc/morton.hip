@@ -50,18 +50,19 @@ __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coor
 }
 
 // The same codes, for col_collide's fused front end: one block per tile of the radix sort (1024 codes
-// below 1 Mi spheres, 4096 up to 16 Mi: col_radix_tile), 4 rows per thread.
+// below 1 Mi spheres, 4096 up to 8 Mi, 8192 above: col_radix_tile), 4 rows per thread and HALVES passes over them
+// (the 8192-code tile is two passes of 1024 threads: the register footprint of the 4096-code one).
 // The block folds the `parts` partial [min row, max row] results of the bounds reduction itself
 // (min/max are exact and order-independent, so every block gets the bits of a stage-2 launch), and
 // counts its tile's digits for the sort's first pass in LDS while the codes are in registers.
 constexpr int MT_ROWS = 4;
-template <typename T, int NT>
+template <typename T, int NT, int HALVES>
 __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ coords, const T *__restrict__ partials,
                                                      u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
                                                      u32 *__restrict__ ids, const T *__restrict__ radii,
                                                      Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
                                                      u32 *__restrict__ hist0, u32 nblocks, int hist_shift, u32 *publish) {
-    constexpr int TILE = NT * MT_ROWS, NW = NT / 64;
+    constexpr int TILE = NT * MT_ROWS * HALVES, NW = NT / 64;
     __shared__ T s_fold[NW][8];
     __shared__ u32 s_hist[256];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -122,22 +123,35 @@ __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ 
         mx.x = r[4]; mx.y = r[5]; mx.z = r[6]; mx.w = r[7];
     }
 #pragma unroll
-    for (int k = 0; k < MT_ROWS; k++) {
-        const u32 i = blockIdx.x * TILE + k * NT + tid;
-        if (i >= padded) continue;
-        u32 code = 0xFFFFFFFFu;   // collision.py:137-142
-        if (i < n) {
-            if (packed) {
-                Vec4<T> pr = c[k];
-                pr.w = rad[k];
-                packed[i] = pr;
+    for (int h = 0; h < HALVES; h++) {
+        if (h > 0) {              // the next MT_ROWS rows of this thread (the first ones were loaded above)
+#pragma unroll
+            for (int k = 0; k < MT_ROWS; k++) {
+                const u32 i = blockIdx.x * TILE + (h * MT_ROWS + k) * NT + tid;
+                if (i < n) {
+                    c[k] = coords[i];
+                    if (packed) rad[k] = radii[i];
+                }
             }
-            code = (expand_bits(quantize(c[k].x, mn.x, mx.x)) << 2) + (expand_bits(quantize(c[k].y, mn.y, mx.y)) << 1) +
-                   expand_bits(quantize(c[k].z, mn.z, mx.z));
         }
-        codes[i] = code;
-        if (ids) ids[i] = i;
-        atomicAdd(&s_hist[(code >> hist_shift) & 255u], 1u);
+#pragma unroll
+        for (int k = 0; k < MT_ROWS; k++) {
+            const u32 i = blockIdx.x * TILE + (h * MT_ROWS + k) * NT + tid;
+            if (i >= padded) continue;
+            u32 code = 0xFFFFFFFFu;   // collision.py:137-142
+            if (i < n) {
+                if (packed) {
+                    Vec4<T> pr = c[k];
+                    pr.w = rad[k];
+                    packed[i] = pr;
+                }
+                code = (expand_bits(quantize(c[k].x, mn.x, mx.x)) << 2) + (expand_bits(quantize(c[k].y, mn.y, mx.y)) << 1) +
+                       expand_bits(quantize(c[k].z, mn.z, mx.z));
+            }
+            codes[i] = code;
+            if (ids) ids[i] = i;
+            atomicAdd(&s_hist[(code >> hist_shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     if (tid < 256) hist0[(uint64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
@@ -149,11 +163,14 @@ int launch_morton_tile(hipStream_t s, u32 tile, const void *coords, const void *
                        uint32_t *hist0, uint32_t nblocks, int hist_shift, uint32_t *publish) {
     dim3 grid(nblocks);
     if (tile == 1024)
-        k_morton_tile<T, 256><<<grid, dim3(256), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                          (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+        k_morton_tile<T, 256, 1><<<grid, dim3(256), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
+                                                             (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+    else if (tile == 4096)
+        k_morton_tile<T, 1024, 1><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
+                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
     else
-        k_morton_tile<T, 1024><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                            (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+        k_morton_tile<T, 1024, 2><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
+                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -166,7 +183,7 @@ int col_morton_tile(void *stream, const void *coords, const void *radii, const v
                     uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
                     uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift, uint32_t *publish) {
     if (padded < n || parts == 0 || !hist0 || hist_shift < 0 || hist_shift > 24) return COL_EINVAL;
-    if (tile != 1024 && tile != 4096) return COL_EINVAL;
+    if (tile != 1024 && tile != 4096 && tile != 8192) return COL_EINVAL;
     if (padded == 0) return COL_OK;
     if (packed && !radii) return COL_EINVAL;
     if (nblocks != (uint32_t)col_ceil_div(padded, tile)) return COL_EINVAL;

@@ -33,14 +33,16 @@ constexpr int BS_SHIFT_REPORT = 22; // == BS_SHIFT below: the MSD plan's bucket 
 // Tile classes (threads x items per thread), template parameters of the kernels:
 //   SMALL 256 x 4  = 1024 pairs  below SMALL_N pairs: a pass is bound by the latency of one block, and
 //                                more, shorter blocks finish sooner (the 1 M-sphere path);
-//   MID   256 x 16 = 4096 pairs  up to BIG_N pairs, and for 8-byte keys (LDS);
+//   MID   256 x 16 = 4096 pairs  up to BIG_N (8 Mi) pairs, and for 8-byte keys (LDS);
 //   BIG   512 x 16 = 8192 pairs  above: the digit runs of a tile are ~128 bytes, a full L2 line, so the
 //                                stores no longer depend on the runs of neighbouring tiles meeting in L2.
 //   HUGE  512 x 32 = 16384 keys  from HUGE_N keys, u32 keys WITHOUT values (k_scatter_huge): ~256-byte runs -- one
 //                                whole line and two partial ones instead of two partial ones per run.
 constexpr int IT_BIG = 16, IT_SMALL = 4, IT_HUGE = 32;
 constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256, NT_HUGE = 512;
-constexpr uint64_t SMALL_N = 1u << 20, BIG_N = 16u << 20, HUGE_N = 32u << 20;   // tools/radix_tile_sweep.py
+// tools/radix_tile_sweep.py.  BIG_N: whole (u32, u32) sorts with the 4096 / 8192 tile at 8 M pairs 0.1772 / 0.1736 ms, 12 M
+// 0.2485 / 0.2367, 16 M 0.3352 / 0.3005 (round 3; it was 16 Mi, taken from a sweep over powers of two)
+constexpr uint64_t SMALL_N = 1u << 20, BIG_N_DEFAULT = 8u << 20, HUGE_N = 32u << 20;
 constexpr int HG = 16;              // max tiles per histogram block (64-byte rows of hist)
 
 template <int B> struct Val;
@@ -760,6 +762,8 @@ __global__ __launch_bounds__(COL_WAVE) void k_ref_scatter(const K *keys, K *keys
 int g_radix_dbg = 0;
 int g_radix_tile_override = 0;      // 0 = automatic, else 1024 / 4096 / 8192 / 16384
 int g_radix_wide_block = 0;         // the 8192-pair tile with 1024 threads x 8 items (experiment, col_debug_radix_tile(8193))
+uint64_t g_big_n = BIG_N_DEFAULT;    // A/B material (col_debug_radix_tile(16 << 20) = the round-2 threshold; buffers sized before a switch do not follow it)
+#define BIG_N g_big_n
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool huge_ok(int key_bytes, int val_bytes) { return key_bytes == 4 && val_bytes == 0; }
 inline u32 tile_auto(uint64_t n, int key_bytes, int val_bytes) {
@@ -938,6 +942,7 @@ void col_debug_radix(int mode) { g_radix_dbg = mode; }
 
 int col_debug_radix_tile(int tile) {
     if (tile == 8193 || tile == 8194) { g_radix_wide_block = tile == 8193; return COL_OK; }      // (8194: back to 512 x 16)
+    if (tile == (16 << 20) || tile == (8 << 20)) { g_big_n = (uint64_t)tile; return COL_OK; }                    // the 4096 / 8192 threshold (A/B)
     if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE) return COL_EINVAL;
     g_radix_tile_override = tile;
     return COL_OK;
