@@ -215,17 +215,18 @@ def test_scratch_sizes_are_monotone_in_n():
     from collision_amd import _lib
     call = _lib.call
     for kb, vb in ((4, 4), (4, 0), (8, 8), (4, 32)):
-        for thr in (1 << 20, 16 << 20):
+        for thr in (1 << 20, 8 << 20, 16 << 20):
             sizes = [call.col_radix_scratch_bytes(n, kb, vb) for n in range(thr - 3000, thr + 3000, 256)]
             assert sizes == sorted(sizes), (kb, vb, thr)
     for cb in (4, 8):
-        for thr in (1 << 20, 16 << 20):
+        for thr in (1 << 20, 8 << 20, 16 << 20):
             ns = list(range(thr - 4096, thr + 4096, 512))
             sizes = [call.col_collide_scratch_bytes(n, n, cb) for n in ns]
             assert sizes == sorted(sizes), (cb, thr)
     # the two cases of the round-1 advisor note
     assert call.col_collide_scratch_bytes(1048064, 1048064, 4) <= call.col_collide_scratch_bytes(1049088, 1049088, 4)
     assert call.col_collide_scratch_bytes(16776704, 16776704, 4) <= call.col_collide_scratch_bytes(16777728, 16777728, 4)
+    assert call.col_collide_scratch_bytes(8388096, 8388096, 4) <= call.col_collide_scratch_bytes(8389120, 8389120, 4)
 
 
 def test_rendered_reductions_compile_without_a_device():

@@ -95,7 +95,7 @@ def test_ref_argsort_loop(hip_env, key_dtype, value_dtype, ngroups, group_size):
 @pytest.mark.parametrize("force_tile", [0, 4096, 8192])
 def test_production_pass(hip_env, key_dtype, val_bytes, n, force_tile):
     """One histogram + scatter pass at a time against NumPy; force_tile runs the 4096- and
-    8192-pair kernels (normally chosen from 1 Mi / 16 Mi elements) on the same small inputs."""
+    8192-pair kernels (normally chosen from 1 Mi / 8 Mi elements) on the same small inputs."""
     call.col_debug_radix_tile(force_tile)
     try:
         _production_pass(hip_env, key_dtype, val_bytes, n)

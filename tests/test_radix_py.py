@@ -148,7 +148,7 @@ def test_sizes_around_the_tile(hip_env):
     from collision_amd._lib import call
     ctx, cq = hip_env
     tile = call.col_radix_tile(1000, 4, 4)             # small inputs use the small tile ...
-    mid, big = 1 << 20, 16 << 20                       # ... then 4096 pairs from here, 8192 from there
+    mid, big = 1 << 20, 8 << 20                        # ... then 4096 pairs from here, 8192 from there
     assert tile < call.col_radix_tile(mid, 4, 4) < call.col_radix_tile(big, 4, 4)
     assert call.col_radix_tile(mid - 1, 4, 4) == tile and call.col_radix_tile(big - 1, 4, 4) == call.col_radix_tile(mid, 4, 4)
     assert call.col_radix_tile(big, 8, 4) == call.col_radix_tile(mid, 4, 4)      # 8-byte keys stop at the middle tile
@@ -166,7 +166,7 @@ def test_sizes_around_the_tile(hip_env):
         np.testing.assert_array_equal(download(cq, vo, np.uint32, n), order.astype(np.uint32))
 
 
-@pytest.mark.parametrize("n", [1000, 4099, 70001, (1 << 20) + 3, (16 << 20) + 3])
+@pytest.mark.parametrize("n", [1000, 4099, 70001, (1 << 20) + 3, (8 << 20) + 3, (16 << 20) + 3])
 def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
     """Keys with one digit per wave (constant, or long constant runs) and a ragged last tile: the
     histogram's wave-uniform shortcut must count only the lanes that are in range."""
@@ -189,7 +189,7 @@ def test_constant_and_blocky_keys_with_ragged_tail(hip_env, n):
                                                  ("uint32", 64), ("uint64", 128)])
 @pytest.mark.parametrize("n", [(1 << 20) + 12345, (16 << 20) + 12345])
 def test_big_tiles_all_type_combinations(hip_env, key_dtype, val_bytes, n):
-    """From 1 Mi elements the sort uses the 4096-pair tile, from 16 Mi the 8192-pair one (4-byte
+    """From 1 Mi elements the sort uses the 4096-pair tile, from 8 Mi the 8192-pair one (4-byte
     keys): every key/value width once in each."""
     from collision_amd._lib import call
     ctx, cq = hip_env
