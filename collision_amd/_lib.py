@@ -11,7 +11,8 @@ import sys
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcollision_hip.so"
+# COLLISION_AMD_LIB: another build of the same ABI (A/B timing of two builds on one box: tools/ab_builds.sh)
+LIB_PATH = Path(os.environ["COLLISION_AMD_LIB"]).resolve() if os.environ.get("COLLISION_AMD_LIB") else _HERE / "libcollision_hip.so"
 
 c_void_pp = C.POINTER(C.c_void_p)
 

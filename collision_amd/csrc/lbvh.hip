@@ -139,7 +139,8 @@ constexpr int WIN = C + 2 * HALO;
 // I: the type of a (possibly out-of-range) leaf position in the Karras search: int32_t below 2^30 leaves --
 // i +- 2 * range cannot overflow it, and 32-bit index arithmetic is half the vector instructions -- else int64_t
 typedef __attribute__((address_space(3))) const u32 LdsWord;
-template <typename I> struct Codes {
+// FAST (32-bit positions only): delta() without per-lane branches, see below.
+template <typename I, bool FAST = false> struct Codes {
     const u32 *__restrict__ g;
     LdsWord *win;              // (an LDS pointer by type: as a generic pointer the two sides of at() become ONE flat_load)
     I w0;
@@ -149,14 +150,32 @@ template <typename I> struct Codes {
         return (o >= 0 && o < WIN) ? win[o] : g[j];
     }
 };
+// v_ffbh_u32: leading zeros, 0xFFFFFFFF for 0
+__device__ __forceinline__ u32 ffbh_raw(u32 x) { u32 r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 // collision.cl:65-77
-template <typename I> __device__ __forceinline__ int delta(const Codes<I> &c, u32 i, u32 ci, I j) {
-    if (j < 0 || j >= (I)c.n) return -1;
-    const u32 cj = c.at(j);
-    return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
+template <typename I, bool FAST> __device__ __forceinline__ int delta(const Codes<I, FAST> &c, u32 i, u32 ci, I j) {
+    if constexpr (FAST && sizeof(I) == 4) {
+        // The plain form below compiles to three nested per-lane branches (range check, window or global memory, equal
+        // codes): ~40 instructions per probe, a third of them scalar EXEC bookkeeping, and a wave makes ~28 probes.  Here:
+        // one wave-uniform branch (does ANY lane's probe leave the code window?  almost never), an unconditional LDS read, and
+        // the tie rule as an unsigned minimum -- clz(ci ^ cj) is 0xFFFFFFFF exactly when the codes are equal, and then
+        // 32 + clz(i ^ j) (j != i in every probe, so that is at most 63) is the smaller one.
+        const bool inb = (u32)j < c.n;                     // 0 <= j < n
+        const u32 o = (u32)(j - c.w0);
+        const bool inwin = o < (u32)WIN;
+        u32 cj;
+        if (__builtin_amdgcn_ballot_w64(inb && !inwin) == 0) cj = c.win[inwin ? o : 0u];
+        else cj = inb ? (inwin ? c.win[o] : c.g[j]) : 0u;
+        const u32 d = min(ffbh_raw(ci ^ cj), 32u + ffbh_raw(i ^ (u32)j));
+        return inb ? (int)d : -1;
+    } else {
+        if (j < 0 || j >= (I)c.n) return -1;
+        const u32 cj = c.at(j);
+        return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz((int)(i ^ (u32)j));
+    }
 }
 // the right child that starts at leaf k (see bvh.hip)
-template <typename I> __device__ __forceinline__ u32 right_child_at(const Codes<I> &c, u32 k) {
+template <typename I, bool FAST> __device__ __forceinline__ u32 right_child_at(const Codes<I, FAST> &c, u32 k) {
     if (k + 1 >= c.n) return (c.n - 1) + k;
     const u32 ck = c.at((I)k);
     const bool fwd = delta(c, k, ck, (I)k + 1) > delta(c, k, ck, (I)k - 1);
@@ -187,7 +206,7 @@ template <typename T> __device__ __forceinline__ void links_store(T *bounds, uin
 template <typename T> struct ChunkLds {
     T leaf[6][C];
     T node[6][C];
-    u32 ready[C];
+    u32 ready[C + 1];                   // [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
     u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
 };
@@ -287,7 +306,7 @@ template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
 __device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
 __device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
 
-template <typename T, bool DIAG, typename I, bool DPP_SCAN = false>
+template <typename T, bool DIAG, typename I, bool DPP_SCAN = false, bool FAST_DELTA = false>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
@@ -312,22 +331,32 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     }
     const u32 c0 = chunk * C;
     const u32 p = c0 + tid;
-    Codes<I> codes = {gcodes, (LdsWord *)s_codes, (I)c0 - HALO, n};
-    for (int o = tid; o < WIN; o += C) {
-        const I j = codes.w0 + o;
-        s_codes[o] = (j >= 0 && j < (I)n) ? gcodes[j] : 0u;
+    Codes<I, FAST_DELTA> codes = {gcodes, (LdsWord *)s_codes, (I)c0 - HALO, n};
+    const bool valid = p < n;
+    // Every independent load of the block first -- the three words of the code window and the leaf's id, at clamped
+    // addresses so that none sits behind a branch -- and ONE wait.  As a loop with the LDS store inside, hipcc waited for
+    // each window load before it issued the next: with the id and the row gather five dependent round trips per block,
+    // now two.
+    u32 wcode[WIN / C];
+#pragma unroll
+    for (int k = 0; k < WIN / C; k++) {
+        const I j = codes.w0 + tid + k * C;
+        const bool in = j >= 0 && j < (I)n;
+        const u32 v = gcodes[in ? j : (I)0];
+        wcode[k] = in ? v : 0u;
     }
+    u32 id = ids[valid ? p : 0u];
+#pragma unroll
+    for (int k = 0; k < WIN / C; k++) s_codes[tid + k * C] = wcode[k];
     lds.ready[tid] = 0;
     if (tid < (int)CROSS_CAP) cross[(uint64_t)chunk * CROSS_CAP + tid] = END;       // (complete before the barrier below: the fence of __syncthreads)
-    if (tid == 0) lds.ncross = 0;
+    if (tid == 0) { lds.ncross = 0; lds.ready[C] = 1u; }
     const u32 leaf_start = n - 1;
-    const bool valid = p < n;
 
     // leaves: collision.cl:55-63 (fillInternal) + collision.cl:128-141 (leafBounds)
     Box<T> leaf = box_empty<T>();
-    u32 id = 0;
+    if (!valid) id = 0;
     if (valid) {
-        id = ids[p];
         const u32 gid = (dbg & 1) ? p : id;
         V4 c;
         T r;
@@ -414,10 +443,13 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         // rounds; finished lanes idle at the loop exit while the others retry.
         const int la = (int)(gamma - c0), lb = la + 1;
         Box<T> box;
+        const int fa = a_leaf ? C : la, fb = b_leaf ? C : lb;      // both flags are read every round, unconditionally
         for (bool done = false; !done;) {
-            const bool ra = a_leaf || __hip_atomic_load(&lds.ready[la], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool rb = b_leaf || __hip_atomic_load(&lds.ready[lb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (ra && rb) {
+            // (relaxed loads + ONE acquire fence on success: two acquire loads are two serial LDS round trips per round)
+            const u32 ra = __hip_atomic_load(&lds.ready[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 rb = __hip_atomic_load(&lds.ready[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ra & rb) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 box = a_leaf ? soa_get(lds.leaf, la) : soa_get(lds.node, la);
                 box_merge(box, b_leaf ? soa_get(lds.leaf, lb) : soa_get(lds.node, lb));
                 soa_put(lds.node, tid, box);
@@ -558,13 +590,17 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
-    // mode bit 10 (1024) alone is not a diagnostics mode: it selects the production instance with the shuffle scans (A/B)
+    // mode bit 10 (1024) alone is not a diagnostics mode: it selects the round-3 production instance -- shuffle scans, branchy
+    // delta() -- for A/Bs (tools/lbvh_scan_ab.py)
     if (g_dbg & ~1024)
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg & ~1024});
     else if (n < (1u << 30) && sizeof(T) == 4 && !(g_dbg & 1024))
-        k_chunk<T, false, int32_t, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                           (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+        k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
+                                                                                 (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+    else if (n < (1u << 30) && !(g_dbg & 1024))
+        k_chunk<T, false, int32_t, false, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
+                                                                                  (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     else if (n < (1u << 30))
         k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
