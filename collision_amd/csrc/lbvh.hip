@@ -145,9 +145,17 @@ template <typename I, bool FAST = false> struct Codes {
     LdsWord *win;              // (an LDS pointer by type: as a generic pointer the two sides of at() become ONE flat_load)
     I w0;
     u32 n;
-    __device__ __forceinline__ u32 at(I j) const {
-        const I o = j - w0;
-        return (o >= 0 && o < WIN) ? win[o] : g[j];
+    __device__ __forceinline__ u32 at(I j) const {          // 0 <= j < n
+        if constexpr (FAST && sizeof(I) == 4) {
+            // one wave-uniform branch instead of a branch per lane (see delta() below)
+            const u32 o = (u32)(j - w0);
+            const bool inwin = o < (u32)WIN;
+            if (__builtin_amdgcn_ballot_w64(!inwin) == 0) return win[o];
+            return inwin ? win[o] : g[j];
+        } else {
+            const I o = j - w0;
+            return (o >= 0 && o < WIN) ? win[o] : g[j];
+        }
     }
 };
 // v_ffbh_u32: leading zeros, 0xFFFFFFFF for 0
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (p >= leaf_start || (dbg & 4)) return;                      // no barrier below this line
 
     // internal node p: collision.cl:81-121 (Karras 2012)
-    const u32 i = p, ci = codes.at((I)i);
+    const u32 i = p, ci = codes.win[HALO + tid];       // (= codes.at(i): the chunk's own codes are always in the window)
     const int dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
     const int delta_min = delta(codes, i, ci, (I)i - dir);
     I len_max = 2;
