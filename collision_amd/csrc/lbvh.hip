@@ -217,6 +217,7 @@ template <typename T> struct ChunkLds {
     u32 ready[C + 1];                   // [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
     u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
+    int adj[C];                         // delta(p, p + 1) of the chunk's own positions (FAST_DELTA: see k_chunk)
 };
 // The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
 // a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
@@ -354,6 +355,19 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         wcode[k] = in ? v : 0u;
     }
     u32 id = ids[valid ? p : 0u];
+    // Adjacent deltas (FAST_DELTA): delta(p - 1, p) and delta(p, p + 1) from two more coalesced loads issued with the
+    // others.  Karras' direction and delta_min of node p are these two numbers (delta_min is the smaller one: three probes
+    // less), and "is the right child that starts at leaf k an internal node" is adj[k] > adj[k - 1] (right_child_at: a
+    // code read and two probes less, twice per thread) wherever k - 1 and k lie in this chunk.
+    int d_prev = -1, d_next = -1;
+    if constexpr (FAST_DELTA && sizeof(I) == 4) {
+        const bool has_prev = valid && p >= 1u, has_next = p + 1u < n;
+        const u32 cprev = gcodes[has_prev ? p - 1u : 0u], cnext = gcodes[has_next ? p + 1u : 0u];
+        const u32 cme = wcode[HALO / C];
+        if (has_prev) d_prev = (int)min(ffbh_raw(cme ^ cprev), 32u + ffbh_raw(p ^ (p - 1u)));
+        if (has_next) d_next = (int)min(ffbh_raw(cme ^ cnext), 32u + ffbh_raw(p ^ (p + 1u)));
+        lds.adj[tid] = d_next;
+    }
 #pragma unroll
     for (int k = 0; k < WIN / C; k++) s_codes[tid + k * C] = wcode[k];
     lds.ready[tid] = 0;
@@ -410,7 +424,16 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (valid) {
         LeafTail tail = {p, id};
         *reinterpret_cast<LeafTail *>(&nodes[leaf_start + p].right_edge) = tail;
-        record_store(bounds, (uint64_t)leaf_start + p, leaf, p + 1 < n ? right_child_at(codes, p + 1) : END, id);
+        u32 skip_leaf = END;
+        if (p + 1 < n) {
+            if constexpr (FAST_DELTA && sizeof(I) == 4) {
+                const u32 k = p + 1;
+                if (k + 1 >= n) skip_leaf = (n - 1) + k;
+                else if (tid + 1 < C) skip_leaf = lds.adj[tid + 1] > d_next ? k : (n - 1) + k;
+                else skip_leaf = right_child_at(codes, k);            // (the chunk's last leaf: adj[k] belongs to the next chunk)
+            } else skip_leaf = right_child_at(codes, p + 1);
+        }
+        record_store(bounds, (uint64_t)leaf_start + p, leaf, skip_leaf, id);
     }
     if (tid == 0)          // chunk total -> level 0 of the first group table
         box_store(tab1, ((uint64_t)(chunk / C) * LV + 0) * C + (chunk % C), suf);
@@ -419,8 +442,14 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
 
     // internal node p: collision.cl:81-121 (Karras 2012)
     const u32 i = p, ci = codes.win[HALO + tid];       // (= codes.at(i): the chunk's own codes are always in the window)
-    const int dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
-    const int delta_min = delta(codes, i, ci, (I)i - dir);
+    int dir, delta_min;
+    if constexpr (FAST_DELTA && sizeof(I) == 4) {
+        dir = d_next > d_prev ? 1 : -1;
+        delta_min = min(d_next, d_prev);                          // = delta(i, i - dir)
+    } else {
+        dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
+        delta_min = delta(codes, i, ci, (I)i - dir);
+    }
     I len_max = 2;
     while (delta(codes, i, ci, (I)i + dir * len_max) > delta_min) len_max *= 2;
     I len = 0;
@@ -443,7 +472,15 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (!(dbg & 2)) { nodes[child_a].parent = i; nodes[child_b].parent = i; }
     other_end[i] = j;
 
-    const u32 skip = hi + 1 < n ? right_child_at(codes, hi + 1) : END;
+    u32 skip = END;
+    if (hi + 1 < n) {
+        if constexpr (FAST_DELTA && sizeof(I) == 4) {
+            const u32 k = hi + 1;
+            if (k + 1 >= n) skip = (n - 1) + k;
+            else if (hi >= c0 && k < c0 + (u32)C) skip = lds.adj[k - c0] > lds.adj[hi - c0] ? k : (n - 1) + k;
+            else skip = right_child_at(codes, k);
+        } else skip = right_child_at(codes, hi + 1);
+    }
     if (dbg & 8) return;
     if (lo >= c0 && hi < c0 + C) {
         // Both children live in this chunk.  Wait (in LDS, workgroup scope) until their boxes are
