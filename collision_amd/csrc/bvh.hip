@@ -1328,8 +1328,8 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
 }
 
 // col_collide_plan with the bounds partials of `coords` already computed (col_minmax4_stage1 / _dev: `parts` records of
-// [min row, max row] at `partials`; NULL = compute them here).  Used where the fused front end applies (below 16 Mi
-// spheres); above it the partials are ignored.
+// [min row, max row] at `partials`; NULL = compute them here).  The fused front end applies at every size of a (u32, u32) sort;
+// only the unfused fallback below (a tile class it does not know) ignores the partials.
 int col_collide_plan_partials(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
                               uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
                               uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,

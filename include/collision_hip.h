@@ -282,7 +282,7 @@ int col_collide_plan(void *stream, const void *coords, const void *radii, uint32
  * (*n_dev, at most n_max; `partials` = 256 records of 8 scalars, *parts = the number written), so it can be enqueued
  * before the host knows the count (the multi-GPU step: right behind col_partition_unpack, while the host still polls
  * for the owned count; the device then has work when the rest of the path arrives).  partials == NULL: as
- * col_collide_plan.  Above 16 Mi spheres (no fused front end) the partials are ignored. */
+ * col_collide_plan.  (The fused front end applies at every size since the end of round 3.) */
 int col_minmax4_stage1_dev(void *stream, const void *rows, const uint32_t *n_dev, uint32_t n_max, int coord_bytes,
                            void *partials, uint32_t *parts);
 int col_collide_plan_partials(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded_size,

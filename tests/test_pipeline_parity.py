@@ -236,8 +236,8 @@ def test_twenty_million_spheres_match_oracle(oracle, hip_env):
 
 
 def test_three_million_spheres_match_oracle(oracle, hip_env):
-    """3 M spheres: the 4096-pair radix tile with the unfused front end (bounds -> Morton -> histogram as
-    separate launches), 11 719 LBVH chunks = 46 groups whose table is built while the top level is
+    """3 M spheres: the 4096-pair radix tile (fused front end: the Morton kernel folds the bounds partials and counts the
+    first digit), 11 719 LBVH chunks = 46 groups whose table is built while the top level is
     scanned linearly; every array bit for bit against the oracle."""
     n = 3000000
     rng = np.random.RandomState(11)
