@@ -3,6 +3,7 @@
 Mirrors the size/dtype/ValueError tests of the reference: tests/test_misc.py, and the
 non-device parts of tests/test_scan_py.py, tests/test_radix_py.py, tests/test_collision_py.py.
 """
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -260,3 +261,18 @@ def test_generic_reduction_restatement_agrees_with_numpy(oracle):
     out = oracle.reduce_list(f, [("INFINITY", "fmin"), ("-INFINITY", "fmax"), ("0", "ADD")], 8, 64)
     np.testing.assert_array_equal(out[:2], np.stack([f.min(0), f.max(0)]))
     np.testing.assert_allclose(out[2], f.sum(0, dtype=np.float64), rtol=1e-5)
+
+
+def test_another_build_of_the_library_can_be_selected():
+    """COLLISION_AMD_LIB names another build of the same ABI (tools/ab_builds.sh times two builds on one box): the binding loads
+    that file, and fails loudly when it does not exist -- there is no fallback."""
+    import sys
+    from collision_amd import _lib
+    code = "from collision_amd import _lib; print(_lib.LIB_PATH); print(_lib.cdll().col_version())"
+    env = dict(os.environ, COLLISION_AMD_LIB=str(_lib._HERE / "libcollision_hip.so"), COLLISION_AMD_NO_TORCH="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(_lib._HERE.parent))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.splitlines()[0].endswith("libcollision_hip.so") and int(out.stdout.splitlines()[1]) >= 1
+    env["COLLISION_AMD_LIB"] = "/nonexistent/libcollision_hip.so"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(_lib._HERE.parent))
+    assert out.returncode != 0
