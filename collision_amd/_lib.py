@@ -67,8 +67,6 @@ _PROTOS = {
                              C.c_int]),
     "col_traverse": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                             C.c_int]),
-    "col_traverse_stats": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
-                                  C.c_void_p, C.c_int]),
     "col_lbvh_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_int]),
     "col_lbvh": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_uint32, C.c_int]),
@@ -107,7 +105,6 @@ _PROTOS = {
     "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_traverse_chunked_scratch_bytes": (C.c_size_t, []),
     "col_traverse_chunked": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                     C.c_void_p]),
@@ -116,6 +113,17 @@ _PROTOS = {
     "col_reduce_rtc_destroy": (C.c_int, [C.c_void_p]),
     "col_reduce_rtc": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p]),
+    "col_gather": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
+    "col_scatter": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
+    "col_find_offsets": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
+}
+
+# diagnostics entry points (include/collision_hip_debug.h): not part of the drop-in ABI; bound for tools/, bench.py's
+# ablation legs and the tests that force a code path
+_DEBUG_PROTOS = {
+    "col_traverse_stats": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+                                  C.c_void_p, C.c_int]),
+    "col_debug_xcc_census": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "col_debug_traverse": (C.c_int, [C.c_int]),
     "col_debug_walk_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "col_debug_lbvh": (C.c_int, [C.c_int]),
@@ -123,12 +131,11 @@ _PROTOS = {
     "col_debug_radix": (C.c_int, [C.c_int]),
     "col_debug_radix_stamps": (None, [C.c_void_p, C.c_int]),
     "col_debug_radix_tile": (None, [C.c_int]),
-    "col_gather": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
-    "col_scatter": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
-    "col_find_offsets": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
 }
 
 EXPORTS = tuple(_PROTOS)
+DEBUG_EXPORTS = tuple(_DEBUG_PROTOS)
+_PROTOS.update(_DEBUG_PROTOS)
 
 
 class HipError(RuntimeError):

@@ -79,6 +79,7 @@ class Collider:
         # the count it is about to zero in a host-visible word: no launch, no sync).
         self.traverse_plan = "auto"
         self._plan_word = None
+        self._last_counter, self._same_counter_calls = None, 0
         self._lsd_calls_left = 0
         self._retry_after = self.PLAN_RETRY
         self._tried_msd = False
@@ -142,6 +143,10 @@ class Collider:
             raise ValueError("Invalid collisions_buf for n_collisions > 0")
         self._allocate()
         cq.wait_for(wait_for)
+        # how many calls in a row have used this counter buffer (see _choose_plan: the published pair count is the
+        # counter's content BEFORE a call zeroes it, which is a previous result only on a buffer that had one)
+        self._same_counter_calls = self._same_counter_calls + 1 if n_collisions_buf.ptr == self._last_counter else 0
+        self._last_counter = n_collisions_buf.ptr
         call.col_collide_plan(
             cq.stream, coords_buf.ptr, radii_buf.ptr, self.size, self.padded_size,
             self.program.coord_dtype.itemsize,
@@ -171,7 +176,11 @@ class Collider:
             return plan | 2
         if self.traverse_plan == "auto" and self._plan_word:
             last = C.c_uint32.from_address(self._plan_word + 8).value
-            if last & 0x80000000 and (last & 0x7FFFFFFF) >= self.DENSE_PAIRS and \
+            # the word is what the counter held when a call zeroed it: on a fresh or rotating counter buffer that is
+            # whatever was in memory, so it only counts once the two previous calls used this same buffer (a host
+            # running further ahead of the device than that can still see the first call's word: the plan is a
+            # choice of speed, never of results)
+            if self._same_counter_calls >= 2 and last & 0x80000000 and (last & 0x7FFFFFFF) >= self.DENSE_PAIRS and \
                     (capacity == 0 or capacity >= (last & 0x7FFFFFFF) + 512 * 8192):
                 return plan | 2
         return plan

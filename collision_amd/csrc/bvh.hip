@@ -1028,16 +1028,28 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     if (g_traverse_variant & 16) mode |= 8;       // plain packet order
     if (g_traverse_variant & 256) mode |= 1;      // timing ablation: skip phase 1 (pairs inside the packets)
     if (g_traverse_variant & 512) mode |= 2;      // timing ablation: skip phase 2 (the walk)
-    static u64 *spread = nullptr;                  // timing ablation: per-wave flush counters (variant bit 10)
+    // (diagnostics buffers: one per device, allocated on first use and kept; variant bits 10 and 13 only)
+    constexpr int MAX_DEV = 16;
+    static u64 *spread_dev[MAX_DEV] = {nullptr};   // timing ablation: per-wave flush counters (variant bit 10)
+    static u32 *dyn_sched_dev[MAX_DEV] = {nullptr};
+    int dev = 0;
+    if (g_traverse_variant & (1024 | 8192)) {
+        COL_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= MAX_DEV) return COL_EINVAL;
+    }
+    u64 *&spread = spread_dev[dev];
     if (g_traverse_variant & 1024) {
         if (!spread && hipMalloc((void **)&spread, 8192 * 32 * 4) != hipSuccess) return COL_EINVAL;
         mode |= 16;
     }
     // the asm walk needs 32-bit record offsets (the record array below 4 GB); variant bit 6 forces the generic loop
-    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
+    // ... and 64-byte aligned records: its leaf-block test fetches candidates with 64-byte scalar loads, which may read up to 32
+    // bytes past the last record -- inside the allocation granule of an aligned array, possibly across a mapping boundary of
+    // a 32-byte aligned sub-allocation (include/collision_hip.h: alignment of `bounds`); anything else takes the generic loop
+    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64) && ((uintptr_t)bounds & 63) == 0;
     // dynamic packet order (k_traverse, mode bit 8): `sched` = eight zeroed words.  Variant bit 13 forces it (with
     // counters of its own, cleared by a memset), bit 14 forbids it: the A/B switches of tools/walk3_ab.py
-    static u32 *dyn_sched = nullptr;
+    u32 *&dyn_sched = dyn_sched_dev[dev];
     if ((g_traverse_variant & 8192) && !sched && !st && !(mode & (32 | 64))) {
         if (!dyn_sched && hipMalloc((void **)&dyn_sched, 64) != hipSuccess) return COL_EINVAL;
         COL_HIP(hipMemsetAsync(dyn_sched, 0, 64, s));
@@ -1197,7 +1209,7 @@ int launch_ghost(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     dim3 g(blocks), t(TT);
     hipStream_t s = col_stream(stream);
     const T *bd = (const T *)bounds;
-    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64);
+    const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64) && ((uintptr_t)bounds & 63) == 0;
     if (off32) k_traverse<T, false, false, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
     else k_traverse<T, false, false, 0, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
     COL_LAUNCH_OK();
@@ -1288,7 +1300,7 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 // asm walk needs); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
-    const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32);
+    const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32) && ((uintptr_t)bounds & 63) == 0;      // (see launch_traverse)
     if (coord_bytes != 4 || !off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
         return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
     if (n < 2) return COL_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/collision_hip.h"
+#include "../../include/collision_hip_debug.h"
 
 #define COL_WAVE 64
 

@@ -40,6 +40,11 @@ constexpr int BS_SHIFT_REPORT = 22; // == BS_SHIFT below: the MSD plan's bucket 
 //                                whole line and two partial ones instead of two partial ones per run.
 constexpr int IT_BIG = 16, IT_SMALL = 4, IT_HUGE = 32;
 constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256, NT_HUGE = 512;
+//   TRI   384 x 16 = 6144 pairs  experiment (col_debug_radix_tile(6144)): 52 KB of LDS and <= 96 VGPRs, so that THREE
+//                                workgroups share a CU (18 waves) instead of two (16): does a third block fill the time in
+//                                which both blocks of the 8192-pair tile have nothing in flight?
+constexpr int NT_TRI = 384;
+constexpr int waves_per_eu_for(int nt) { return nt == NT_TRI ? 5 : nt / 256; }
 // tools/radix_tile_sweep.py.  BIG_N: whole (u32, u32) sorts with the 4096 / 8192 tile at 8 M pairs 0.1772 / 0.1736 ms, 12 M
 // 0.2485 / 0.2367, 16 M 0.3352 / 0.3005 (round 3; it was 16 Mi, taken from a sweep over powers of two)
 constexpr uint64_t SMALL_N = 1u << 20, BIG_N_DEFAULT = 8u << 20, HUGE_N = 32u << 20;
@@ -157,7 +162,7 @@ template <int SCOPE, typename X> __device__ __forceinline__ void st_scope(X *p, 
 template <bool NARROW> struct CntType { typedef u32 T; };
 template <> struct CntType<true> { typedef uint16_t T; };
 template <typename K, int VB, int IT, int NT, bool DIAG>
-__global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+__global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
                                                 const u32 *__restrict__ offsets, typename DiagArg<DIAG>::T diag) {
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     __shared__ __attribute__((aligned(16))) V s_vals[V_LDS ? TILE : 1];
     // (wave, digit) counters: at most 64 * IT items per wave and TILE per block, so 16 bits do when a block has 16 waves --
     // with 32-bit counters the 1024-thread instance would not fit two blocks into a CU's LDS
-    typedef typename CntType<(NT > 512)>::T CNT;
+    typedef typename CntType<(NT > 512 || NT == NT_TRI)>::T CNT;
     __shared__ CNT s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
     __shared__ u32 s_ws[NW];
@@ -185,7 +190,13 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     // XCD a contiguous range of tiles: the ~64-byte runs of neighbouring tiles then meet in one L2 and
     // leave it as full lines instead of partial-line writes from 8 different L2s.  (Speed only.)
     u32 b = blockIdx.x;
-    if (!(dbg & 4)) {
+    if (DIAG && (dbg & (1 << 22)) && nblocks % (8u << ((dbg >> 24) & 7)) == 0) {
+        // (diagnostics, mode 1 << 22: STRIPS of G = 1 << ((mode >> 24) & 7) consecutive tiles go round the XCDs instead of one
+        // contiguous range per XCD: the resident workgroups then cover ONE window of consecutive tiles, i.e. one contiguous
+        // piece of every digit's output region, and only every G-th pair of neighbouring tiles meets in different L2s)
+        const u32 G = 1u << ((dbg >> 24) & 7), x = b % 8, j = b / 8;
+        b = ((j / G) * 8 + x) * G + (j % G);
+    } else if (!(dbg & 4)) {
         const u32 q = nblocks / 8, r = nblocks % 8, xcd = b % 8;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
@@ -777,6 +788,7 @@ inline u32 tile_for(uint64_t n, int key_bytes, int val_bytes) {
     u32 t = (u32)g_radix_tile_override;
     if (t > (u32)(NT_BIG * IT_BIG) && !huge_ok(key_bytes, val_bytes)) t = (u32)(NT_BIG * IT_BIG);
     if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
+    if (t == (u32)(NT_TRI * IT_BIG) && !(val_bytes == 0 || val_bytes == 4)) t = (u32)(NT_BIG * IT_BIG);     // (the experiment: u32 keys, no / 4-byte values)
     return t;
 }
 inline u32 tiles_of(uint64_t n, int key_bytes, int val_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes, val_bytes)); }
@@ -811,6 +823,7 @@ int launch_hist(hipStream_t s, const void *keys, uint64_t n, int val_bytes, int 
     if (tile == (u32)(NT_SMALL * IT_SMALL)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else if (tile == (u32)(NT_MID * IT_BIG)) k_hist<K, NT_MID * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else if (tile == (u32)(NT_BIG * IT_BIG)) k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
+    else if (tile == (u32)(NT_TRI * IT_BIG)) k_hist<K, NT_TRI * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else k_hist<K, NT_HUGE * IT_HUGE><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
@@ -874,6 +887,11 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
                 COL_LAUNCH_OK();
             }
             return COL_OK;
+        }
+        if (tile == (u32)(NT_TRI * IT_BIG)) {
+            const u32 nb = (u32)col_ceil_div(n, NT_TRI * IT_BIG);
+            if (vb == 0) return launch_scatter_one<K, 0, IT_BIG, NT_TRI>(s, (const K *)keys, (K *)keys_out, nullptr, nullptr, n, nb, shift, offsets);
+            return launch_scatter_one<K, 4, IT_BIG, NT_TRI>(s, (const K *)keys, (K *)keys_out, vals, vals_out, n, nb, shift, offsets);
         }
         // the 8192-pair tile as 1024 threads x 8 items (32 waves per CU instead of 16, same LDS): col_debug_radix_tile(8193)
         if (g_radix_wide_block && (vb == 0 || vb == 4 || vb == 8))
@@ -943,7 +961,8 @@ void col_debug_radix(int mode) { g_radix_dbg = mode; }
 int col_debug_radix_tile(int tile) {
     if (tile == 8193 || tile == 8194) { g_radix_wide_block = tile == 8193; return COL_OK; }      // (8194: back to 512 x 16)
     if (tile == (16 << 20) || tile == (8 << 20)) { g_big_n = (uint64_t)tile; return COL_OK; }                    // the 4096 / 8192 threshold (A/B)
-    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE) return COL_EINVAL;
+    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE &&
+        tile != NT_TRI * IT_BIG) return COL_EINVAL;
     g_radix_tile_override = tile;
     return COL_OK;
 }

@@ -524,7 +524,10 @@ class HipEngine(ProtocolOps):
             # scratch for the packet walk: coarse Morton keys + record numbers of every slot entry, sorted (csrc/multi.hip)
             need = call.col_ghost_scratch_bytes(n_in, slot)
             if self._ghost_scratch is None or self._ghost_scratch.numel() < need:
-                self._ghost_scratch = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+                # written and read on the main stream only; this may run while the halo branch's side stream is torch's
+                # current one (_drive), and the caching allocator ties a block to the stream that is current when it is made
+                with self.torch.cuda.stream(self.main):
+                    self._ghost_scratch = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
             scratch = self._ghost_scratch.data_ptr()
         call.col_traverse_ghost_slots(self.cq.stream, self.halo_recv.data_ptr(), n_in, slot,
                                       self.collider._bounds_buf.ptr, self.n_owned, owned_gids.data_ptr(),

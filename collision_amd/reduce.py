@@ -16,6 +16,7 @@ whatever ``ngroups`` and ``group_size`` are (the reference's halving loop drops 
 powers of two).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -213,6 +214,11 @@ extern "C" __global__ void bounds2(const S *__restrict__ group_accs, S *__restri
     return _PRELUDE + body
 
 
+class _BadInitialValue(ValueError):
+    """A NUMERIC initial value the accumulator's dtype cannot hold (out of range / not an integer): rejected, where a
+    value that is not a number at all is an expression for the compiler."""
+
+
 def _parse_init(text, dtype):
     """(value as a double, value as an exact 64-bit integer or None).  The reference renders the text verbatim into
     the kernel; here it must be a number or [-]INFINITY.  Integer dtypes take integer initial values exactly
@@ -231,12 +237,12 @@ def _parse_init(text, dtype):
     except ValueError:
         value = float(text)
         if value != int(value):
-            raise ValueError("Initial value {} is not an integer ({} accumulator)".format(text, base))
+            raise _BadInitialValue("Initial value {} is not an integer ({} accumulator)".format(text, base))
         exact = int(value)
     value = float(exact)
     info = np.iinfo(base)
     if not info.min <= exact <= info.max:
-        raise ValueError("Initial value {} outside the range of {}".format(text, base))
+        raise _BadInitialValue("Initial value {} outside the range of {}".format(text, base))
     return value, exact - (1 << 64) if exact >= (1 << 63) else exact
 
 
@@ -274,9 +280,9 @@ class ReductionProgram(ProgramHandle):
             return False
         try:
             parsed = [_parse_init(init, self.value_dtype) for init, _ in key]
-        except ValueError as e:
-            if "range" in str(e) or "integer" in str(e):
-                raise
+        except _BadInitialValue:
+            raise
+        except ValueError:
             return False                           # an initial value that is an expression: let the compiler read it
         self.acc_ops = (C.c_int * len(key))(*[_ACC_FN[fn] for _, fn in key])
         self.acc_inits = (C.c_double * len(key))(*[v for v, _ in parsed])
@@ -287,7 +293,7 @@ class ReductionProgram(ProgramHandle):
 
     def __del__(self):
         rtc, self.rtc = getattr(self, "rtc", None), None
-        if rtc:
+        if rtc and not sys.is_finalizing():        # (at interpreter shutdown the HIP runtime may be gone already)
             try:
                 cdll().col_reduce_rtc_destroy(rtc)
             except Exception:

@@ -189,7 +189,12 @@ int col_bvh_refit(void *stream, void *bounds, uint32_t *flags, const void *coord
 /* Replaces traverse (collision/collision.py:191-196, collision/collision.cl:
  * 174-226).  counter: 1 uint32 zeroed by the caller, receives the TOTAL hit
  * count; pairs may be NULL when capacity == 0.  Needs the links written by
- * col_bvh_build(bounds != NULL). */
+ * col_bvh_build(bounds != NULL).
+ * Alignment of `bounds` (here and in col_traverse_chunked, col_collide*, col_traverse_ghost_slots): any 32-byte
+ * aligned pointer is accepted; the fast walk (f32 records below 4 GB) is taken when it is 64-byte aligned -- what
+ * col_malloc / hipMalloc / a torch allocation give -- because its leaf-block test uses 64-byte scalar loads, which
+ * may read up to 32 bytes past the last record (never used, but inside the allocation of an aligned array).  Other
+ * pointers take the generic walk: same pairs, slower. */
 int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                  const col_node *nodes, const void *bounds, uint32_t n, int coord_bytes);
 
@@ -201,32 +206,6 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 size_t col_traverse_chunked_scratch_bytes(void);
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch);
-
-/* Diagnostics build of the same traversal: stats[0] += node visits, stats[1] += loop trips per
- * wave (slowest lane), stats[2] += waves (3 x uint64, zeroed by the caller). */
-int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
-int col_debug_walk_profile(uint32_t *out, uint32_t npackets);   /* diagnostics: see csrc/bvh.hip */
-void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
-void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off; 1024 alone = the production instance with the
-                                         * round-3 code (shuffle scans, branchy Karras probes) for A/Bs, not a diagnostics instance */
-void col_debug_leaf_blocks(float k);    /* leaf-block criterion of col_lbvh (process-wide): a node of <= 16 leaves is marked when it is at
-                                         * most k leaf boxes wide on every axis; default 3, 0 = no marks, a huge k = every small node */
-/* The col_debug_* switches are PROCESS-WIDE and unsynchronised: they select separate diagnostics instances of the
- * kernels for every caller in the process (the production instances carry no diagnostics code).  Set them from one
- * thread while no work is in flight; col_collide / col_collide_plan refuse to run under a forced tile class. */
-void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
-                                           64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU,
-                                           32768 = every store lands in a 4 MiB window, 65536 = ranking skipped on a tile-sorted input,
-                                           1 << 21 = ranks from returning LDS atomics (experiment, csrc/radix.hip) */
-int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192, 16384; 0 = automatic).  Set it BEFORE sizing
-                                           scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it.
-                                           8 << 20 / 16 << 20: where the 8192-pair tile takes over from the 4096-pair one (default 8 Mi pairs;
-                                           A/B material, not a forced class -- buffers sized before the switch do not follow it);
-                                           8193 / 8194: the 8192-pair tile as 1024 x 8 / 512 x 16 (default) */
-int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
-/* stats: 8 x uint64 (steps, descents, leaf tests, leaf hits, steps within 1k/2k/4k/8k positions of the block start) */
-int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
-                       const void *bounds, uint32_t n, int coord_bytes, uint64_t *stats, int mode);
 
 /* Fused production form of the three calls above minus the traversal: Karras topology, leaf and
  * internal AABBs and the traversal links in one pass, with no inter-workgroup hand-off (node

@@ -26,15 +26,19 @@ def ctx():
 def test_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "collision_hip.h").read_text()
     declared = set(re.findall(r"\b(col_[a-z0-9_]+)\s*\(", header))
+    # diagnostics live in a header of their own: not part of the drop-in ABI, but exported for tools/
+    debug = set(re.findall(r"\b(col_[a-z0-9_]+)\s*\(", (ROOT / "include" / "collision_hip_debug.h").read_text()))
+    assert not any(name.startswith("col_debug") for name in declared) and not (declared & debug)
     lib = _lib.cdll()
     exported = {line.split()[-1] for line in
                 subprocess.check_output(["nm", "-D", str(_lib.LIB_PATH)]).decode().splitlines()
                 if " T " in line}
     assert declared, "no declarations parsed"
     # built with -fvisibility=hidden: the .so exports exactly what the header declares, internal helpers stay inside
-    assert declared == exported, declared ^ exported
+    assert declared | debug == exported, (declared | debug) ^ exported
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    for name in declared:
+    assert debug == set(_lib.DEBUG_EXPORTS), debug ^ set(_lib.DEBUG_EXPORTS)
+    for name in declared | debug:
         assert hasattr(lib, name)
     assert lib.col_version() >= 100
     assert _lib.call.col_radix_tile(1 << 26, 4, 4) % 256 == 0 and _lib.call.col_radix_tile(1000, 4, 4) % 256 == 0
