@@ -40,11 +40,13 @@ constexpr int BS_SHIFT_REPORT = 22; // == BS_SHIFT below: the MSD plan's bucket 
 //                                whole line and two partial ones instead of two partial ones per run.
 constexpr int IT_BIG = 16, IT_SMALL = 4, IT_HUGE = 32;
 constexpr int NT_BIG = 512, NT_MID = 256, NT_SMALL = 256, NT_HUGE = 512;
-//   TRI   384 x 16 = 6144 pairs  experiment (col_debug_radix_tile(6144)): 52 KB of LDS and <= 96 VGPRs, so that THREE
-//                                workgroups share a CU (18 waves) instead of two (16): does a third block fill the time in
-//                                which both blocks of the 8192-pair tile have nothing in flight?
-constexpr int NT_TRI = 384;
-constexpr int waves_per_eu_for(int nt) { return nt == NT_TRI ? 5 : nt / 256; }
+// COL_SCATTER_KEYS_FIRST = 1: k_scatter waits for its keys only and ranks them while the value loads are still in flight.
+// Measured in round 4 (two builds alternating on one box, 3 x 100 launches each, EXPERIMENTS.md): 0.2556 ms per 64 Mi-pair
+// pass against 0.2328 -- like the pass with its ranking taken away (round 3), a workgroup that reaches its store phase
+// sooner makes the pass SLOWER.  Off.
+#ifndef COL_SCATTER_KEYS_FIRST
+#define COL_SCATTER_KEYS_FIRST 0
+#endif
 // tools/radix_tile_sweep.py.  BIG_N: whole (u32, u32) sorts with the 4096 / 8192 tile at 8 M pairs 0.1772 / 0.1736 ms, 12 M
 // 0.2485 / 0.2367, 16 M 0.3352 / 0.3005 (round 3; it was 16 Mi, taken from a sweep over powers of two)
 constexpr uint64_t SMALL_N = 1u << 20, BIG_N_DEFAULT = 8u << 20, HUGE_N = 32u << 20;
@@ -105,48 +107,66 @@ __device__ __forceinline__ u64 match8(u32 d) {
 }
 
 // ---- histogram: blocks handle `g` consecutive tiles and write g-entry rows per digit ----
+// Round 4.  The first version counted with LDS atomics on a plain 256-bin array: 64 lanes with ~57 distinct random digits
+// hit 32 banks, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 70 % (profiles/r03_radix64M_pmc.json), and the kernel read at
+// 4.7 TB/s where an in-order sweep reaches 6 (MI355X_MICROARCH.md).  Now every bin has HC = 16 COLUMNS, lane l counts in
+// column l % 16 of its digit: the word address is d * 16 + (l % 16), i.e. bank 16 * (d % 2) + l % 16 -- the two lanes of a
+// 32-lane group that share a column collide only when their digits have the same parity, which an LDS atomic (4 cycles of
+// address + data transfer per wave-instruction) hides.  After a tile thread d folds its 16 columns (four 16-byte reads,
+// rotated by d / 4 so that the 16 lanes of a read group cover all 64 banks) and clears them for the next tile.
+// A wave-uniform digit (sorted inputs) puts 4 lanes on each of 16 addresses instead of 64 on one: no special case.
 // (amdgpu_num_sgpr: above 80 SGPRs a wave's allocation -- with the 16 the trap handler reserves on this platform -- no
-// longer lets 8 waves share a SIMD; unconstrained, hipcc takes 102 here for the unrolled ballots)
+// longer lets 8 waves share a SIMD)
+constexpr int HC = 16;              // columns per bin
 template <typename K, int TILE>
 __global__ __launch_bounds__(RT) __attribute__((amdgpu_num_sgpr(80))) void k_hist(const K *__restrict__ keys, uint64_t n, u32 nblocks, u32 g,
                                              int shift, u32 *__restrict__ hist) {
     constexpr int IT = TILE / RT;
-    __shared__ u32 h[HG * RDIG];
-    const u32 tid = threadIdx.x;
-    for (u32 i = tid; i < g * RDIG; i += RT) h[i] = 0;
+    constexpr int VEC = 16 / sizeof(K);          // keys per 16-byte load
+    constexpr int NV = IT / VEC;                 // 16-byte loads per thread and tile
+    __shared__ __attribute__((aligned(16))) u32 col[RDIG * HC];      // 16 KB
+    __shared__ u32 h[HG * RDIG];                                     // 16 KB: the block's g rows
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32 tid = threadIdx.x, c = tid & (HC - 1);
+#pragma unroll
+    for (int j = 0; j < HC / 4; j++) *reinterpret_cast<v4u *>(col + tid * HC + 4 * j) = v4u{0, 0, 0, 0};
     __syncthreads();
     const u32 b0 = blockIdx.x * g;
-    for (u32 t = 0; t < g && b0 + t < nblocks; t++) {
+    const u32 cnt = min(g, nblocks - b0);
+    for (u32 t = 0; t < cnt; t++) {
         const uint64_t base = (uint64_t)(b0 + t) * TILE;
-        u32 *ht = h + t * RDIG;
-        constexpr int VEC = 16 / sizeof(K);          // keys per 16-byte load
+        if (base + TILE <= n) {
+            v4u q[NV];
 #pragma unroll
-        for (int k = 0; k < IT / VEC; k++) {
-            const uint64_t i = base + ((uint64_t)k * RT + tid) * VEC;
-            if (i + VEC <= n) {
+            for (int k = 0; k < NV; k++) q[k] = *reinterpret_cast<const v4u *>(keys + base + ((uint64_t)k * RT + tid) * VEC);
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
                 K kk[VEC];
-                *reinterpret_cast<uint4 *>(kk) = *reinterpret_cast<const uint4 *>(keys + i);
+                *reinterpret_cast<v4u *>(kk) = q[k];
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    // sorted or low-entropy inputs put one digit in every lane; 64 LDS atomics on one
-                    // address would serialise, so a wave-uniform digit is counted with a single add
-                    const u32 d = digit_of(kk[j], shift);
-                    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-                    // (only the lanes inside this branch take part: the ragged last tile is partly elsewhere)
-                    const u64 active = __ballot(true);
-                    if (__ballot(d != d0) == 0) {
-                        if (lane_id() == (u32)__builtin_ctzll(active)) atomicAdd(&ht[d0], (u32)__popcll(active));
-                    } else atomicAdd(&ht[d], 1u);
-                }
-            } else {
-                for (int j = 0; j < VEC; j++)
-                    if (i + j < n) atomicAdd(&ht[digit_of(keys[i + j], shift)], 1u);
+                for (int j = 0; j < VEC; j++) atomicAdd(&col[digit_of(kk[j], shift) * HC + c], 1u);
+            }
+        } else {
+            for (int k = 0; k < IT; k++) {
+                const uint64_t i = base + (uint64_t)k * RT + tid;
+                if (i < n) atomicAdd(&col[digit_of(keys[i], shift) * HC + c], 1u);
             }
         }
+        __syncthreads();
+        {   // digit `tid`: fold the columns, clear them
+            u32 sum = 0;
+#pragma unroll
+            for (int j = 0; j < HC / 4; j++) {
+                v4u *p = reinterpret_cast<v4u *>(col + tid * HC + 4 * ((j + (tid >> 2)) & (HC / 4 - 1)));
+                const v4u v = *p;
+                sum += v.x + v.y + v.z + v.w;
+                *p = v4u{0, 0, 0, 0};
+            }
+            h[t * RDIG + tid] = sum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // thread d writes its row of up to g entries (contiguous: full-sector writes)
-    const u32 cnt = min(g, nblocks - b0);
     u32 *row = hist + (uint64_t)tid * nblocks + b0;
     for (u32 t = 0; t < cnt; t++) row[t] = h[t * RDIG + tid];
 }
@@ -162,7 +182,7 @@ template <int SCOPE, typename X> __device__ __forceinline__ void st_scope(X *p, 
 template <bool NARROW> struct CntType { typedef u32 T; };
 template <> struct CntType<true> { typedef uint16_t T; };
 template <typename K, int VB, int IT, int NT, bool DIAG>
-__global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+__global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                 const void *__restrict__ vals_in_, void *__restrict__ vals_out_,
                                                 uint64_t n, u32 nblocks, int shift,
                                                 const u32 *__restrict__ offsets, typename DiagArg<DIAG>::T diag) {
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *_
     __shared__ __attribute__((aligned(16))) V s_vals[V_LDS ? TILE : 1];
     // (wave, digit) counters: at most 64 * IT items per wave and TILE per block, so 16 bits do when a block has 16 waves --
     // with 32-bit counters the 1024-thread instance would not fit two blocks into a CU's LDS
-    typedef typename CntType<(NT > 512 || NT == NT_TRI)>::T CNT;
+    typedef typename CntType<(NT > 512)>::T CNT;
     __shared__ CNT s_cnt[NW][RDIG];
     __shared__ u32 s_goff[RDIG];
     __shared__ u32 s_ws[NW];
@@ -214,23 +234,28 @@ __global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *_
     K key[IT];
     V val[V_LDS ? IT : 1];
     constexpr int KV = 16 / sizeof(K);                    // keys per 16-byte load
-    if (valid == (u32)TILE && !(dbg & 8)) {
+    constexpr int VV = 16 / sizeof(V);
+    constexpr int NVQ = V_LDS ? IT / VV : 0;              // 16-byte value loads per thread
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    v4u vq[V_LDS ? IT / VV : 1];
+    V *vstage = s_vals + w * (COL_WAVE * IT);
+    const bool full = valid == (u32)TILE && !(dbg & 8);
+    if (full) {
         // Full tile: 16-byte global loads (lane l takes KV consecutive keys), transposed to the
         // lane-striped order the ranking needs through this wave's own slice of the LDS staging
         // area.  LDS operations of one wave execute in order, so no barrier is needed.
         // All global loads of the tile (keys AND values) are issued before the first wait: one memory
-        // round trip per tile instead of two.
+        // round trip per tile instead of two.  Round 4: the wave then waits for its KEYS only -- vmcnt counts in
+        // issue order, the NVQ value loads were issued after them -- and ranks them while the values are still on
+        // their way; the values are waited for, transposed and taken into registers after the ranking.
         K *stage = s_keys + w * (COL_WAVE * IT);
         const K *src = keys_in + tile_base + w * (COL_WAVE * IT);
-        constexpr int VV = 16 / sizeof(V);
-        V *vstage = s_vals + w * (COL_WAVE * IT);
         const V *vsrc = vals_in + tile_base + w * (COL_WAVE * IT);
         // The loads are asm statements: hipcc sinks a plain second group of loads below the first
         // group's LDS writes (to save registers), which serialises two round trips.  hipcc does not
-        // count asm loads, so every destination passes through an explicit vmcnt(0) statement before
+        // count asm loads, so every destination passes through an explicit vmcnt statement before
         // its first use (cdna_hip_programming.md 5.7, form ii).
-        typedef u32 v4u __attribute__((ext_vector_type(4)));
-        v4u kq[IT / KV], vq[V_LDS ? IT / VV : 1];
+        v4u kq[IT / KV];
         if (dbg & 64) {                          // timing ablation: non-temporal (streaming) loads
 #pragma unroll
             for (int j = 0; j < IT / KV; j++)
@@ -250,26 +275,17 @@ __global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *_
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vq[j]) : "v"(vsrc + j * (COL_WAVE * VV) + lane * VV) : "memory");
             }
         }
+        // (NO control flow between an asm load and its wait: with a run-time choice between two waits here hipcc placed
+        // register copies of the load destinations in front of the waits -- it does not know they are in flight -- and the
+        // kernel ranked garbage.  COL_SCATTER_KEYS_FIRST = 0 builds the round-3 behaviour for A/Bs: tools/ab_radix.sh.)
 #pragma unroll
-        for (int j = 0; j < IT / KV; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(kq[j])::"memory");
-        if (V_LDS) {
-#pragma unroll
-            for (int j = 0; j < IT / VV; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq[j])::"memory");
-        }
+        for (int j = 0; j < IT / KV; j++) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(kq[j]) : "n"(COL_SCATTER_KEYS_FIRST ? NVQ : 0) : "memory");
 #pragma unroll
         for (int j = 0; j < IT / KV; j++)
             *reinterpret_cast<v4u *>(stage + j * (COL_WAVE * KV) + lane * KV) = kq[j];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < IT; k++) key[k] = stage[k * COL_WAVE + lane];
-        if (V_LDS) {
-#pragma unroll
-            for (int j = 0; j < IT / VV; j++)
-                *reinterpret_cast<v4u *>(vstage + j * (COL_WAVE * VV) + lane * VV) = vq[j];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < IT; k++) val[k] = vstage[k * COL_WAVE + lane];
-        }
     } else {
 #pragma unroll
         for (int k = 0; k < IT; k++) {
@@ -281,6 +297,21 @@ __global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *_
             for (int k = 0; k < IT; k++) {
                 const u32 li = wbase + k * COL_WAVE;
                 if (li < valid) val[k] = vals_in[tile_base + li];
+            }
+        }
+        // These loads must be waited for HERE, inside the branch.  Left pending, they reach the join with the full-tile
+        // path as "registers that may still be loading", and hipcc then puts an s_waitcnt vmcnt(0) in front of the
+        // full-tile path's first write to any of them -- which (read in the ISA, round 4) made every full tile wait for
+        // the round trip of `my_offset` BEFORE issuing its loads -- and another one behind the join, which would undo the
+        // overlap of the ranking with the value loads.  An empty asm that "uses" each register makes hipcc wait here.
+#pragma unroll
+        for (int k = 0; k < IT; k++) asm volatile("" : "+v"(key[k]));
+        if (V_LDS) {
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                u32 *words = reinterpret_cast<u32 *>(&val[k]);
+#pragma unroll
+                for (int c = 0; c < (int)(sizeof(V) / 4); c++) asm volatile("" : "+v"(words[c]));
             }
         }
     }
@@ -314,6 +345,17 @@ __global__ __launch_bounds__(NT, waves_per_eu_for(NT)) void k_scatter(const K *_
         if (below == 0) s_cnt[w][d] = (CNT)(prev + (u32)__popcll(peers));
         pos[k] = prev + below;
     }
+    }
+    if (V_LDS && full) {
+        // the values: in flight since the top of the kernel, through this wave's slice of the value image
+#pragma unroll
+        for (int j = 0; j < IT / VV; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq[j])::"memory");
+#pragma unroll
+        for (int j = 0; j < IT / VV; j++)
+            *reinterpret_cast<v4u *>(vstage + j * (COL_WAVE * VV) + lane * VV) = vq[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < IT; k++) val[k] = vstage[k * COL_WAVE + lane];
     }
     __syncthreads();
     STAMP(1)      // ranking
@@ -788,7 +830,6 @@ inline u32 tile_for(uint64_t n, int key_bytes, int val_bytes) {
     u32 t = (u32)g_radix_tile_override;
     if (t > (u32)(NT_BIG * IT_BIG) && !huge_ok(key_bytes, val_bytes)) t = (u32)(NT_BIG * IT_BIG);
     if (key_bytes == 8 && t > (u32)(NT_MID * IT_BIG)) t = (u32)(NT_MID * IT_BIG);
-    if (t == (u32)(NT_TRI * IT_BIG) && !(val_bytes == 0 || val_bytes == 4)) t = (u32)(NT_BIG * IT_BIG);     // (the experiment: u32 keys, no / 4-byte values)
     return t;
 }
 inline u32 tiles_of(uint64_t n, int key_bytes, int val_bytes) { return (u32)col_ceil_div(n, tile_for(n, key_bytes, val_bytes)); }
@@ -823,7 +864,6 @@ int launch_hist(hipStream_t s, const void *keys, uint64_t n, int val_bytes, int 
     if (tile == (u32)(NT_SMALL * IT_SMALL)) k_hist<K, NT_SMALL * IT_SMALL><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else if (tile == (u32)(NT_MID * IT_BIG)) k_hist<K, NT_MID * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else if (tile == (u32)(NT_BIG * IT_BIG)) k_hist<K, NT_BIG * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
-    else if (tile == (u32)(NT_TRI * IT_BIG)) k_hist<K, NT_TRI * IT_BIG><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     else k_hist<K, NT_HUGE * IT_HUGE><<<grid, block, 0, s>>>(k, n, nb, g, pass * 8, hist);
     COL_LAUNCH_OK();
     return COL_OK;
@@ -887,11 +927,6 @@ int launch_scatter(hipStream_t s, const void *keys, void *keys_out, const void *
                 COL_LAUNCH_OK();
             }
             return COL_OK;
-        }
-        if (tile == (u32)(NT_TRI * IT_BIG)) {
-            const u32 nb = (u32)col_ceil_div(n, NT_TRI * IT_BIG);
-            if (vb == 0) return launch_scatter_one<K, 0, IT_BIG, NT_TRI>(s, (const K *)keys, (K *)keys_out, nullptr, nullptr, n, nb, shift, offsets);
-            return launch_scatter_one<K, 4, IT_BIG, NT_TRI>(s, (const K *)keys, (K *)keys_out, vals, vals_out, n, nb, shift, offsets);
         }
         // the 8192-pair tile as 1024 threads x 8 items (32 waves per CU instead of 16, same LDS): col_debug_radix_tile(8193)
         if (g_radix_wide_block && (vb == 0 || vb == 4 || vb == 8))
@@ -961,8 +996,7 @@ void col_debug_radix(int mode) { g_radix_dbg = mode; }
 int col_debug_radix_tile(int tile) {
     if (tile == 8193 || tile == 8194) { g_radix_wide_block = tile == 8193; return COL_OK; }      // (8194: back to 512 x 16)
     if (tile == (16 << 20) || tile == (8 << 20)) { g_big_n = (uint64_t)tile; return COL_OK; }                    // the 4096 / 8192 threshold (A/B)
-    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE &&
-        tile != NT_TRI * IT_BIG) return COL_EINVAL;
+    if (tile != 0 && tile != NT_SMALL * IT_SMALL && tile != NT_MID * IT_BIG && tile != NT_BIG * IT_BIG && tile != NT_HUGE * IT_HUGE) return COL_EINVAL;
     g_radix_tile_override = tile;
     return COL_OK;
 }

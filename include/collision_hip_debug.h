@@ -29,7 +29,8 @@ void col_debug_leaf_blocks(float k);    /* leaf-block criterion of the fused LBV
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
                                            64 = non-temporal loads, 128/256 = system/agent-scope stores, 512/1024 = fewer blocks per CU,
                                            32768 = every store lands in a 4 MiB window, 65536 = ranking skipped on a tile-sorted input,
-                                           1 << 21 = ranks from returning LDS atomics (experiment, csrc/radix.hip) */
+                                           1 << 21 = ranks from returning LDS atomics (experiment, csrc/radix.hip),
+                                           1 << 22 | log2(G) << 24 = strips of G tiles go round the XCDs instead of one tile range per XCD */
 int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (1024, 4096, 8192, 16384; 0 = automatic).  Set it BEFORE sizing
                                            scratch with col_radix_scratch_bytes / col_radix_tile: the histogram layout follows it.
                                            8 << 20 / 16 << 20: where the 8192-pair tile takes over from the 4096-pair one (default 8 Mi pairs;
