@@ -111,51 +111,33 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         res[name + "_mean"] = sum(each) / len(each)
         res[name + "_p10_p90"] = (each[len(each) // 10], each[(9 * len(each)) // 10])
 
-    # The ceiling of the pass's ACCESS PATTERN on this box: the kernel itself -- same loads, same LDS staging, same stores
-    # at the same addresses -- with the ranking taken away (diagnostics mode 65536), run on the pass's tile-sorted image
-    # (which mode 2 writes).  `hist` still holds pass 0's scanned histogram.
-    pattern = None
+    # What a read-n-write-n pass can reach on THIS box, in the same run (col_debug_copy, csrc/radix.hip): the plain float4
+    # copy (one vector per thread: the fastest form found, EXPERIMENTS.md R4.1) and the scatter pass's own tile shape --
+    # 64 KB per 512-thread workgroup through LDS, coalesced stores -- with no ranking.  Same bytes as the pass (1 GiB moved),
+    # interleaved with the production kernel.
+    ceiling = None
     try:
-        from collision_amd._lib import cdll
-        simg_k, simg_v = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
-        cdll().col_debug_radix(2)
-        call.col_radix_scatter(cq.stream, kin.ptr, simg_k.ptr, vin.ptr, simg_v.ptr, n, 4, 4, 0, hist.ptr)
-        cq.finish()
-        cdll().col_debug_radix(0)
-        call.col_radix_scatter(cq.stream, kin.ptr, kout.ptr, vin.ptr, vout.ptr, n, 4, 4, 0, hist.ptr)      # the real pass
-        pk, pv = hip.Buffer(ctx, n * 4), hip.Buffer(ctx, n * 4)
+        src, dst = hip.Buffer(ctx, n * 8), hip.Buffer(ctx, n * 8)
+        call.col_memcpy_d2d(cq.stream, src.ptr, kin.ptr, n * 4)
+        call.col_memcpy_d2d(cq.stream, src.ptr + n * 4, vin.ptr, n * 4)
 
-        def store_pattern():       # (mode 65536: the kernel itself on its tile-sorted image, ranking skipped)
-            call.col_radix_scatter(cq.stream, simg_k.ptr, pk.ptr, simg_v.ptr, pv.ptr, n, 4, 4, 0, hist.ptr)
-        cdll().col_debug_radix(65536)
-        store_pattern()
-        cq.finish()
-        cdll().col_debug_radix(0)
-        got_k, want_k = hip.read_buffer(cq, pk, np.uint32, n), hip.read_buffer(cq, kout, np.uint32, n)
-        got_v, want_v = hip.read_buffer(cq, pv, np.uint32, n), hip.read_buffer(cq, vout, np.uint32, n)
-        same = bool((got_k == want_k).all() and (got_v == want_v).all())
-        del got_k, want_k, got_v, want_v
-        def timed(mode, fn):
-            cdll().col_debug_radix(mode)
-            for _ in range(40):
+        def series(fn):
+            for _ in range(20):
                 fn()
             cq.finish()
-            each = time_events_each(hip, cq, fn, SCATTER_TIMED)
-            cdll().col_debug_radix(0)
-            return each
-        # three interleaved series on the same box state: the ranking-free kernel on the sorted image; the SAME
-        # diagnostics instance doing the full production work (mode bit 20 is a no-op: the instance carries the
-        # diagnostic branches and is a few per cent slower than the production one); the production instance
-        each = timed(65536, store_pattern)
-        diag_full = timed(1 << 20, scatter)
-        again = timed(0, scatter)
-        pattern = {"launch_ms": each[len(each) // 2], "p10_p90": (each[len(each) // 10], each[(9 * len(each)) // 10]),
-                   "diag_instance_full_work_ms": diag_full[len(diag_full) // 2],
-                   "kernel_ms_right_after": again[len(again) // 2], "same_output_as_the_pass": same}
-        del simg_k, simg_v, pk, pv
+            each = time_events_each(hip, cq, fn, SCATTER_TIMED // 2)
+            return each[len(each) // 2], (each[len(each) // 10], each[(9 * len(each)) // 10])
+        ceiling = {}
+        for name, shape in (("float4_copy", 0), ("tile_shape_copy", 1)):
+            ms, p1090 = series(lambda: call.col_debug_copy(cq.stream, src.ptr, dst.ptr, n * 8, shape))
+            ceiling[name] = {"launch_ms": ms, "p10_p90": p1090}
+        ms, p1090 = series(scatter)
+        ceiling["k_scatter_right_after"] = {"launch_ms": ms, "p10_p90": p1090}
+        got = hip.read_buffer(cq, dst, np.uint32, 1 << 20)
+        ceiling["copied_correctly"] = bool((got == keys[:1 << 20]).all())
+        del src, dst
     except Exception as exc:                                    # (diagnostics leg: never lose the bench line over it)
-        pattern = {"error": repr(exc)}
-        cdll().col_debug_radix(0)
+        ceiling = {"error": repr(exc)}
 
     def histo():
         call.col_radix_histogram(cq.stream, kin.ptr, n, 4, 4, 0, hist.ptr)
@@ -169,7 +151,7 @@ def radix_microbench(hip, ctx, cq, n=SORT_KEYS, reps=5):
         "scatter_ms": scatter_ms, "scatter_ms_top_digit": res["pass3"], "hist_ms": hist_ms,
         "scatter_gbs": algo_bytes / scatter_ms / 1e6,
         "scatter_ms_cold": res["pass0_cold"], "scatter_ms_mean": res["pass0_mean"], "scatter_ms_p10_p90": res["pass0_p10_p90"],
-        "algo_bytes_per_launch": algo_bytes, "pattern": pattern,
+        "algo_bytes_per_launch": algo_bytes, "copy_ceiling": ceiling,
     }
 
 
@@ -226,6 +208,24 @@ def single_gpu_leg(hip, ctx, cq, n, reps=20):
     return {"spheres": n, "ms_per_step": round(ms, 4), "m_spheres_per_s": round(n / ms / 1e3, 1),
             "pairs": int(hip.read_buffer(cq, nb, np.uint32, 1)[0]),
             "compulsory_gb_per_s": round(gbs, 1), "compulsory_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def config2_f64_leg(hip, ctx, cq, reps=20):
+    """BASELINE config 2's scene with float64 coordinates (the reference's tests run both dtypes, tests/test_collision.py:20-29)."""
+    from collision_amd.collision import Collider
+    coords, radii = uniform_scene(N_SPHERES)
+    cb, rb = hip.Buffer(ctx, hostbuf=coords.astype(np.float64)), hip.Buffer(ctx, hostbuf=radii.astype(np.float64))
+    nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, PAIR_CAPACITY * 8)
+    col = Collider(ctx, N_SPHERES, NGROUPS, GROUP_SIZE, coord_dtype="float64")
+
+    def run():
+        col.get_collisions(cq, cb, rb, nb, pb, PAIR_CAPACITY)
+    for _ in range(5):
+        run()
+    cq.finish()
+    ms = time_events(hip, cq, run, reps)
+    return {"workload": "BASELINE config 2 with float64 coordinates and radii", "ms_per_step": round(ms, 4),
+            "m_spheres_per_s": round(N_SPHERES / ms / 1e3, 1), "pairs": int(hip.read_buffer(cq, nb, np.uint32, 1)[0])}
 
 
 def config5_variants(hip, ctx, cq, n=SORT_KEYS, reps=3):
@@ -531,6 +531,8 @@ def main():
         pair_count = int(hip.read_buffer(cq, n_buf, np.uint32, 1)[0])
     else:
         pair_count = engine.global_pair_count()
+        extra["dist_backend"] = dist.get_backend()
+        extra["world_size_seen"] = dist.get_world_size()
         extra["per_rank"] = {"owned_spheres_rank0": engine.stats.get("owned"), "ghost_queries_rank0": engine.stats.get("ghosts"),
                              "partition_slot_records": engine.stats.get("partition_slot"),
                              "halo_slot_records": engine.stats.get("halo_slot"), "repeated_steps": engine.repeats}
@@ -587,20 +589,22 @@ def main():
                         "launches_timed": SCATTER_TIMED, "warmup_launches": SCATTER_WARMUP,
                         "launch_ms_first_20_after_idle": round(rb["scatter_ms_cold"], 4),
                         "traffic": None}
-            pat = rb.get("pattern")
-            if pat and "launch_ms" in pat:
-                # the memory side of the same pass with the ranking taken away: what the access pattern -- ~128-byte runs at
-                # 4-byte alignment -- allows on THIS box; the kernel is measured against it
-                roofline["pattern_ceiling"] = {
-                    "what": "the kernel on its tile-sorted image with the ranking skipped: same loads, LDS staging and stores (col_debug_radix 65536)",
-                    "launch_ms": round(pat["launch_ms"], 4), "launch_ms_p10_p90": [round(v, 4) for v in pat["p10_p90"]],
-                    "frac_of_hbm_peak": round(rb["algo_bytes_per_launch"] / pat["launch_ms"] / 1e6 / HBM_PEAK_GBS, 4),
-                    "same_instance_with_ranking_ms": round(pat["diag_instance_full_work_ms"], 4),
-                    "ranking_costs": round(pat["diag_instance_full_work_ms"] / pat["launch_ms"] - 1.0, 4),
-                    "production_kernel_ms_right_after": round(pat["kernel_ms_right_after"], 4),
-                    "same_output_as_the_pass": pat["same_output_as_the_pass"]}
-            elif pat:
-                roofline["pattern_ceiling"] = pat
+            cc = rb.get("copy_ceiling")
+            if cc and "float4_copy" in cc:
+                def frac(ms):
+                    return round(rb["algo_bytes_per_launch"] / ms / 1e6 / HBM_PEAK_GBS, 4)
+                roofline["copy_ceiling"] = {
+                    "what": "a pass that reads n bytes and writes n bytes, same 1 GiB, same run (col_debug_copy): the plain float4 "
+                            "copy (one vector per thread) and the scatter pass's tile shape (64 KB per 512-thread workgroup "
+                            "through LDS, coalesced stores) without ranking; the pass pays for its ranking and its scattered runs on top",
+                    "float4_copy_ms": round(cc["float4_copy"]["launch_ms"], 4), "float4_copy_frac_of_hbm_peak": frac(cc["float4_copy"]["launch_ms"]),
+                    "tile_shape_copy_ms": round(cc["tile_shape_copy"]["launch_ms"], 4),
+                    "tile_shape_copy_frac_of_hbm_peak": frac(cc["tile_shape_copy"]["launch_ms"]),
+                    "k_scatter_ms_right_after": round(cc["k_scatter_right_after"]["launch_ms"], 4),
+                    "k_scatter_frac_of_float4_copy": round(cc["float4_copy"]["launch_ms"] / cc["k_scatter_right_after"]["launch_ms"], 4),
+                    "copied_correctly": cc["copied_correctly"]}
+            elif cc:
+                roofline["copy_ceiling"] = cc
             if world == 1 and not args.no_pmc:
                 roofline["traffic"], roofline["traffic_detail"] = pmc_traffic()
                 roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of tools/radix_only.py in this "
@@ -619,6 +623,7 @@ def main():
             extra["count_only_pairs"] = int(hip.read_buffer(cq, n_buf, np.uint32, 1)[0])
             if not args.no_radix:
                 extra["config3_clustered"] = config3_leg(hip, ctx, cq)
+                extra["config2_f64"] = config2_f64_leg(hip, ctx, cq)
                 extra["radix_sort"]["gkeys_per_s_other_distributions"] = config5_variants(hip, ctx, cq)
                 extra["config4_per_rank_size_on_one_gpu"] = single_gpu_leg(hip, ctx, cq, N_PER_RANK_MULTI)
                 # config 4's whole scene on ONE GPU: the regime where the path runs out of HBM, not out of the caches

@@ -129,6 +129,7 @@ _DEBUG_PROTOS = {
     "col_debug_lbvh": (C.c_int, [C.c_int]),
     "col_debug_leaf_blocks": (C.c_int, [C.c_float]),
     "col_debug_radix": (C.c_int, [C.c_int]),
+    "col_debug_copy": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "col_debug_radix_stamps": (None, [C.c_void_p, C.c_int]),
     "col_debug_radix_tile": (None, [C.c_int]),
 }

@@ -777,6 +777,78 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                 if (!hits) break;                                           // the chain ended (idx == END, no block pending)
                 sink.emit(hits, qid, pid);                                  // the staging area was full: flush, then stage;
             }                                                               // then on: the rest of the block (bcnt), the skip link (idx)
+        } else if constexpr (sizeof(T) == 8 && WALK == 1 && !VEC) {
+            // The asm walk for float64 records (round 4): a record is 64 bytes -- {min.xyz, skip}{max.xyz, down} as doubles, the
+            // links in the low words of the fourth lanes -- fetched by ONE s_load_dwordx16 into s[40:55] at a 32-bit offset
+            // (node << 6; arrays below 4 GB), tested with six v_cmpx_*_f64 against the lanes' boxes (SGPR pair against VGPR
+            // pair), and the whole walk stays inside one asm loop as for float32: a miss follows the skip link (s46), a hit
+            // internal node the down link (s54), a hit leaf stages its pairs right there.  Marked nodes (leaf blocks) are entered
+            // through their first leaf and the leaves' skip links lead through the block (exact: col_common.h); a candidate
+            // loop like float32's would need three 64-byte records in flight, which the 80-SGPR budget does not hold.
+            const char *rows_b = reinterpret_cast<const char *>(rows);
+            const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;
+            while (idx != END) {
+                u64 hits, exec0;
+                u32 pid, v0, v1;
+                asm volatile("s_mov_b64 %[exec0], exec\n\t"
+                             "s_mov_b32 s46, %[idx]\n"
+                             "1:\n\t"
+                             "s_lshl_b32 %[t0], s46, 6\n\t"                // s46: the node to fetch, then its skip link
+                             "s_load_dwordx16 s[40:55], %[base], %[t0]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_cmpx_lt_f64_e32 vcc, s[40:41], %[hx]\n\t"   // lo.x < my hi.x
+                             "v_cmpx_gt_f64_e32 vcc, s[48:49], %[lx]\n\t"   // hi.x > my lo.x
+                             "v_cmpx_lt_f64_e32 vcc, s[42:43], %[hy]\n\t"
+                             "v_cmpx_gt_f64_e32 vcc, s[50:51], %[ly]\n\t"
+                             "v_cmpx_lt_f64_e32 vcc, s[44:45], %[hz]\n\t"
+                             "v_cmpx_gt_f64_e32 vcc, s[52:53], %[lz]\n\t"
+                             "s_cbranch_execnz 2f\n\t"                     // somebody overlaps
+                             "s_mov_b64 exec, %[exec0]\n"
+                             "8:\n\t"
+                             "s_cmp_lg_u32 s46, -1\n\t"                    // nobody (or the leaf is done): follow the skip link
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 %[idx], -1\n\t"
+                             "s_mov_b64 %[hits], 0\n\t"
+                             "s_branch 4f\n"
+                             "2:\n\t"
+                             "s_cmp_ge_u32 %[t0], %[leaf]\n\t"
+                             "s_cbranch_scc1 3f\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_mov_b32 s46, s54\n\t"                      // an internal node: descend (down link) ...
+                             "s_bitcmp1_b32 s54, 31\n\t"
+                             "s_cbranch_scc0 1b\n\t"
+                             "s_bfe_u32 s46, s54, 0x1b0004\n\t"            // ... or, a leaf block: on through its leaf chain
+                             "s_add_u32 s46, s46, %[leafidx]\n\t"
+                             "s_branch 1b\n"
+                             "3:\n\t"                                       // a leaf: stage (my id, its id) for the hit lanes
+                             "s_bcnt1_i32_b64 %[t0], exec\n\t"
+                             "s_add_u32 %[t0], %[cnt], %[t0]\n\t"
+                             "s_cmp_gt_u32 %[t0], 512\n\t"                 // CAPW
+                             "s_cbranch_scc1 5f\n\t"
+                             "v_mbcnt_lo_u32_b32 %[v0], exec_lo, 0\n\t"
+                             "v_mbcnt_hi_u32_b32 %[v0], exec_hi, %[v0]\n\t"
+                             "v_add_u32 %[v0], %[cnt], %[v0]\n\t"
+                             "v_lshl_add_u32 %[v0], %[v0], 3, %[buf]\n\t"
+                             "v_mov_b32 %[v1], s54\n\t"
+                             "ds_write2_b32 %[v0], %[qid], %[v1] offset1:1\n\t"
+                             "s_mov_b32 %[cnt], %[t0]\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_branch 8b\n"
+                             "5:\n\t"                                       // the staging area is full: let the sink flush it
+                             "s_mov_b64 %[hits], exec\n\t"
+                             "s_mov_b64 exec, %[exec0]\n\t"
+                             "s_mov_b32 %[t0], s54\n\t"                    // the hit leaf's id
+                             "s_mov_b32 %[idx], s46\n"                      // where the walk goes on: behind the leaf
+                             "4:"
+                             : [idx] "+s"(idx), [cnt] "+s"(sink.count), [hits] "=&s"(hits), [exec0] "=&s"(exec0),
+                               [t0] "=&s"(pid), [v0] "=&v"(v0), [v1] "=&v"(v1)
+                             : [base] "s"(rows_b), [leaf] "s"(leaf_start * 64u), [leafidx] "s"(leaf_start), [buf] "s"(buf_lds),
+                               [qid] "v"(qid), [hx] "v"(hx), [hy] "v"(hy), [hz] "v"(hz), [lx] "v"(lx), [ly] "v"(ly), [lz] "v"(lz)
+                             : "vcc", "scc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+                               "s51", "s52", "s53", "s54", "s55");
+                if (!hits) break;                                           // the chain ended
+                sink.emit(hits, qid, pid);                                  // the staging area was full: flush, then stage; then on
+            }
         } else if constexpr (sizeof(T) == 4 && WALK == 2 && !VEC) {
             typedef int v8i __attribute__((ext_vector_type(8)));
             const char *rows_b = reinterpret_cast<const char *>(rows);
@@ -1296,15 +1368,17 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 
 // col_traverse for scenes with millions of pairs: the same pair list, but the workgroups take list space in chunks of
 // 8192 pairs (one atomic on the counter per chunk instead of one per 512 pairs) and a small kernel closes the holes at
-// the end.  *counter must be 0 on entry (the list starts here).  f32 coordinates and record arrays below 4 GB (what the
-// asm walk needs); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
+// the end.  *counter must be 0 on entry (the list starts here).  Record arrays below 4 GB and 64-byte aligned (what the
+// asm walks need); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
-    const bool off32 = (2ull * n - 1) * 8 * 4 < (1ull << 32) && ((uintptr_t)bounds & 63) == 0;      // (see launch_traverse)
-    if (coord_bytes != 4 || !off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
+    const bool off32 = (coord_bytes == 4 || coord_bytes == 8) && (2ull * n - 1) * 8 * (unsigned)coord_bytes < (1ull << 32) &&
+                       ((uintptr_t)bounds & 63) == 0;                                                // (see launch_traverse)
+    if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
         return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
+    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch);      // (round 4: the asm walk has a float64 form)
     return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch);
 }
 

@@ -987,9 +987,60 @@ int gather_values(hipStream_t s, const void *in, const u32 *idx, void *out, uint
     return COL_OK;
 }
 
+// ---- copy ceilings (diagnostics: bench.py's roofline.copy_ceiling; tools/micro/copy_ceiling.hip has the full set) ----
+// What a pass that reads n bytes and writes n bytes can reach on this box, measured beside the scatter pass:
+//   shape 0: the plain float4 copy, ONE 16-byte vector per thread, one-shot grid -- the fastest form found (more vectors per
+//            thread, grid-strided or persistent grids are all slower: EXPERIMENTS.md R4.1);
+//   shape 1: the scatter pass's own shape -- one 512-thread workgroup per 64 KB tile, all of its loads issued up front, the
+//            tile staged through 64 KB of LDS, coalesced dword stores, XCD-contiguous tile order -- with no ranking at all.
+__global__ __launch_bounds__(256) void k_dbg_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t nvec) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nvec) out[i] = in[i];
+}
+__global__ __launch_bounds__(NT_BIG) void k_dbg_tile_copy(const u32 *__restrict__ in, u32 *__restrict__ out, uint64_t half_words) {
+    constexpr int TILE = NT_BIG * IT_BIG;               // 8192 "pairs": 32 KB from each half of the buffer
+    __shared__ __attribute__((aligned(16))) u32 s_k[TILE], s_v[TILE];
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 q = gridDim.x / 8, r = gridDim.x % 8, xcd = blockIdx.x % 8;
+    const u32 b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blockIdx.x / 8;
+    const uint64_t base = (uint64_t)b * TILE;
+    const u32 *ka = in + base + w * 1024 + lane * 4, *va = in + half_words + base + w * 1024 + lane * 4;
+    v4u kq[4], vq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kq[j]) : "v"(ka + j * 256) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vq[j]) : "v"(va + j * 256) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(kq[j])::"memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq[j])::"memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        *reinterpret_cast<v4u *>(s_k + w * 1024 + j * 256 + lane * 4) = kq[j];
+        *reinterpret_cast<v4u *>(s_v + w * 1024 + j * 256 + lane * 4) = vq[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IT_BIG; k++) {
+        const u32 i = k * NT_BIG + tid;
+        out[base + i] = s_k[i];
+        out[half_words + base + i] = s_v[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int col_debug_copy(void *stream, const void *in, void *out, uint64_t bytes, int shape) {
+    if (!in || !out || bytes == 0 || bytes % (2 * NT_BIG * IT_BIG * 4) != 0) return COL_EINVAL;      // whole tiles in both halves
+    if (shape == 0) k_dbg_copy<<<dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, col_stream(stream)>>>((const uint4 *)in, (uint4 *)out, bytes / 16);
+    else if (shape == 1) k_dbg_tile_copy<<<dim3((unsigned)(bytes / (2 * NT_BIG * IT_BIG * 4))), dim3(NT_BIG), 0, col_stream(stream)>>>((const u32 *)in, (u32 *)out, bytes / 8);
+    else return COL_EINVAL;
+    COL_LAUNCH_OK();
+    return COL_OK;
+}
 
 void col_debug_radix(int mode) { g_radix_dbg = mode; }
 

@@ -202,7 +202,7 @@ int col_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
  * chunks of 8192 pairs -- one atomic on the counter per chunk instead of one per 512 pairs, which is what bounds the walk
  * on BASELINE config 3 (50 000 atomics on one address) -- and a small kernel closes the holes the chunks leave; if the
  * chunks ran past `capacity` the exact walk runs again (4 launches instead of 1).  *counter must be 0 on entry.
- * f32 and record arrays below 4 GB; anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes(). */
+  * record arrays below 4 GB and 64-byte aligned (f32 and, since round 4, f64); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes(). */
 size_t col_traverse_chunked_scratch_bytes(void);
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch);

@@ -36,7 +36,11 @@ int col_debug_radix_tile(int tile);     /* diagnostics: force the tile class (10
                                            8 << 20 / 16 << 20: where the 8192-pair tile takes over from the 4096-pair one (default 8 Mi pairs;
                                            A/B material, not a forced class -- buffers sized before the switch do not follow it);
                                            8193 / 8194: the 8192-pair tile as 1024 x 8 / 512 x 16 (default) */
-int col_debug_radix_stamps(uint64_t *out8, int reset);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
+int col_debug_radix_stamps(uint64_t *out8, int reset);
+/* copies `bytes` (a multiple of 128 KiB) from `in` to `out`: shape 0 = float4 copy, one vector per thread; shape 1 = the scatter
+ * pass's tile shape (64 KB per 512-thread workgroup through LDS, coalesced stores) without any ranking: bench.py's
+ * roofline.copy_ceiling, measured beside the pass */
+int col_debug_copy(void *stream, const void *in, void *out, uint64_t bytes, int shape);   /* diagnostics: cycles per k_scatter phase, summed over blocks */
 /* Diagnostics build of the traversal -- same pairs, same counter semantics -- that also counts its work.
  * stats: 8 x uint64, zeroed by the caller (steps, descents, leaf tests, leaf hits, steps within 1k/2k/4k/8k positions
  * of the block start) */

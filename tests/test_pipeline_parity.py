@@ -68,6 +68,32 @@ def test_uniform_scene_matches_oracle(oracle, hip_env, dtype, n, r, gs):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_box_edges_at_signed_zero(oracle, hip_env, dtype):
+    """Box edges at -0.0 and +0.0.  The refit's unions are v_min / v_max instructions (csrc/lbvh.hip), which return -0 for
+    min(-0, +0) and +0 for max whatever the order, where the reference's `y < x ? y : x` (collision.cl:157) keeps whichever
+    came first: the two can differ in the SIGN of a zero, never in value.  So: node boxes equal BY VALUE (assert_array_equal
+    treats -0 == +0), every other array bit for bit, and the same pair set -- touching boxes (an edge of one at +0, of the
+    other at -0) do not collide, boxes that straddle zero do."""
+    rng = np.random.RandomState(4)
+    n = 4096
+    coords = (rng.random_sample((n, 3)) * 2 - 1).astype(dtype) * np.asarray(0.05, dtype)
+    radii = np.full(n, 0.004, dtype=dtype)
+    # zero-radius spheres at -0.0 and +0.0 (boxes [-0, +0] and [+0, +0]), spheres whose box ends exactly at zero from
+    # either side (c = +-r), and spheres that straddle zero
+    coords[0] = (-0.0, -0.0, -0.0); radii[0] = 0.0
+    coords[1] = (0.0, 0.0, 0.0); radii[1] = 0.0
+    for k, sign in ((2, 1.0), (3, -1.0), (4, 1.0), (5, -1.0)):
+        radii[k] = 0.002 if k < 4 else 0.003
+        coords[k] = sign * radii[k]                       # lo (or hi) = c - r = exactly +0.0 (or c + r = -r + r = +0.0)
+    coords[6] = (0.001, -0.001, 0.0005); radii[6] = 0.002
+    coords[7] = (-0.0005, 0.0, -0.0); radii[7] = 0.001
+    lo, hi = coords[:8] - radii[:8, None], coords[:8] + radii[:8, None]
+    assert (np.signbit(lo) & (lo == 0)).any() and (~np.signbit(hi) & (hi == 0)).any()      # both zeros do occur as edges
+    _, st, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=64)
+    assert count > 0
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_clustered_scene_matches_oracle(oracle, hip_env, dtype):
     coords, radii = clustered_scene(20000, 0.01, 0.002, dtype)
     _, _, count, _ = check_against_oracle(oracle, hip_env, coords, radii, group_size=256)

@@ -53,6 +53,16 @@ if [ "$1" = "profiles" ]; then
     done
     python tools/summarize_prof.py pmc $dbs > $S/path1M_pmc.json && rm -rf $O/path_pmc_*
     echo "path pmc ok"
+    # per-kernel durations of the headline configuration alone (config 2, 1 M spheres), f32 and f64
+    for dt in float32 float64; do
+        rm -rf $O/path1M_$dt
+        ( cd /tmp && COLLISION_PATH_DTYPE=$dt timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/path1M_$dt -o kt -- python3 $R/tools/path_only.py 50 1000000 > $O/path1M_$dt.log 2>&1 ) \
+            || { tail -20 $O/path1M_$dt.log; exit 1; }
+        { echo "# rocprofv3 --kernel-trace --stats -- python3 tools/path_only.py 50 1000000   (BASELINE config 2, $dt coordinates: 50 steps, every launch of the path)"
+          python tools/summarize_prof.py stats $O/path1M_$dt/kt_results.db; } > $S/path1M_${dt}_kernel_stats.txt
+        rm -rf $O/path1M_$dt
+    done
+    echo "path 1M kernel stats ok"
     exit 0
 fi
 # profiles2

@@ -1,6 +1,7 @@
 """Runs only the single-GPU path a few times, for rocprofv3 passes.
     python tools/path_only.py [steps] [n_spheres] [plan: auto|lsd|msd] [scene: uniform|config3] [leaf-block k] [traverse variant]
-(leaf-block k: col_debug_leaf_blocks, 0 = no marks; traverse variant: col_debug_traverse, 128 = the walk without block code)"""
+(leaf-block k: col_debug_leaf_blocks, 0 = no marks; traverse variant: col_debug_traverse, 128 = the walk without block code;
+COLLISION_PATH_DTYPE=float64 in the environment: float64 coordinates and radii)"""
 import os
 import sys
 
@@ -22,7 +23,8 @@ else:
     coords, radii = bench.uniform_scene(n)
     radii[:] = bench.RADIUS * (1e6 / n) ** (1.0 / 3.0)
     cap = bench.PAIR_CAPACITY * 8
-cb, rb = hip.Buffer(ctx, hostbuf=coords), hip.Buffer(ctx, hostbuf=radii)
+dtype = os.environ.get("COLLISION_PATH_DTYPE", "float32")
+cb, rb = hip.Buffer(ctx, hostbuf=coords.astype(dtype)), hip.Buffer(ctx, hostbuf=radii.astype(dtype))
 nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
 if len(sys.argv) > 5:
     import ctypes
@@ -32,7 +34,7 @@ if len(sys.argv) > 5:
     lib.col_debug_leaf_blocks(ctypes.c_float(float(sys.argv[5])))
     if len(sys.argv) > 6:
         lib.col_debug_traverse(int(sys.argv[6]))
-col = Collider(ctx, n, bench.NGROUPS, bench.GROUP_SIZE)
+col = Collider(ctx, n, bench.NGROUPS, bench.GROUP_SIZE, coord_dtype=dtype)
 col.sort_plan = plan
 for _ in range(steps):
     col.get_collisions(cq, cb, rb, nb, pb, cap)

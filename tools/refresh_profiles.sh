@@ -1,20 +1,22 @@
 #!/bin/bash
 # After `tools/final_gpu_run.sh tests`, `... profiles` and `... profiles2` on the GPU box: copy the summaries the box
-# condensed (gpurun_out/summary/) into the committed profiles/ files of round $ROUND (default r03).
+# condensed (gpurun_out/summary/) into the committed profiles/ files of round $ROUND (default r04).
 set -e
 cd "$(dirname "$0")/.."
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 S=gpurun_out/summary
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-pmc   (MI355X, default K=50 W=10; summarised by"
   echo "# tools/summarize_prof.py from the rocpd results db).  k_scatter<unsigned int, 4, 16, 512, false> aggregates every launch of"
   echo "# the 64 Mi-pair instance in the run: the roofline leg's pass-0 and pass-3 series (cold + warm-up + timed), and all four digit"
   echo "# passes of every whole sort (30-bit, uniform-32 and arange keys; arange pass 0 is the 0.4 ms outlier that lifts the average);"
-  echo "# the <.., true> instance is the pattern-ceiling leg (diagnostics modes).  bench.py's roofline = MEDIAN of 200 steady-state"
+  echo "# k_dbg_copy / k_dbg_tile_copy are the copy-ceiling leg (roofline.copy_ceiling).  bench.py's roofline = MEDIAN of 200 steady-state"
   echo "# pass-0 launches (one HIP event per launch): compare with median_us.  k_traverse / k_chunk rows: the 1 M path (config 2) plus"
   echo "# the config-3 (clustered, 25 M pairs: chunked allocation + k_pairs_compact), 2 M and 16 M steps and the reference's benchmark shapes."
   cat $S/bench_kernel_stats.txt; } > profiles/${R}_bench_kernel_stats.txt
 cp $S/radix64M_pmc.json profiles/${R}_radix64M_pmc.json
 cp $S/path1M_pmc.json profiles/${R}_path1M_pmc.json
+cp $S/path1M_float32_kernel_stats.txt profiles/${R}_path1M_kernel_stats.txt
+cp $S/path1M_float64_kernel_stats.txt profiles/${R}_path1M_f64_kernel_stats.txt
 for tag in 2M 16M; do
     cp $S/path${tag}_kernel_stats.txt profiles/${R}_path${tag}_kernel_stats.txt
     cp $S/path${tag}_pmc.json profiles/${R}_path${tag}_pmc.json
