@@ -301,6 +301,51 @@ __device__ __forceinline__ void wave_suffix_union(Box<float> &b) {
 #undef COL_SCAN6
 #undef COL_DOWN6
 #undef COL_APPLY6
+// The same scans for float64 boxes (round 4: the f64 kernel shuffled its twelve doubles through 144 x 2 ds_bpermute and took
+// 76.6 us at 1 M spheres against 51 for f32).  There is no v_min_f64 with a DPP operand, so a step moves the two words of a
+// value with v_mov_b32_dpp (a lane the shift does not reach keeps its own value: `old` = the source) and merges with
+// v_min / v_max_f64; hipcc places the wait states of the builtins itself.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(u32)b, hi = (int)(u32)((u64)b >> 32);
+    const u32 l2 = (u32)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const u32 h2 = (u32)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((u64)h2 << 32) | l2));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void box_dpp_merge(Box<double> &b) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = hw_min(b.lo[k], dpp_d<CTRL, ROW_MASK>(b.lo[k]));
+        b.hi[k] = hw_max(b.hi[k], dpp_d<CTRL, ROW_MASK>(b.hi[k]));
+    }
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)b >> 32), l);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ void wave_prefix_union(Box<double> &b) {
+    box_dpp_merge<0x111, 0xF>(b);       // row_shr:1, 2, 4, 8 inside the rows of 16
+    box_dpp_merge<0x112, 0xF>(b);
+    box_dpp_merge<0x114, 0xF>(b);
+    box_dpp_merge<0x118, 0xF>(b);
+    box_dpp_merge<0x142, 0xA>(b);       // row_bcast:15 -> rows 1, 3
+    box_dpp_merge<0x143, 0xC>(b);       // row_bcast:31 -> rows 2, 3
+}
+__device__ __forceinline__ void wave_suffix_union(Box<double> &b) {
+    box_dpp_merge<0x101, 0xF>(b);       // row_shl:1, 2, 4, 8
+    box_dpp_merge<0x102, 0xF>(b);
+    box_dpp_merge<0x104, 0xF>(b);
+    box_dpp_merge<0x108, 0xF>(b);
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int first = 48; first >= 16; first -= 16) {      // row 3's total -> rows 0..2, rows 2..3 -> rows 0..1, rows 1..3 -> row 0
+        Box<double> t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { t.lo[k] = readlane_d(b.lo[k], first); t.hi[k] = readlane_d(b.hi[k], first); }
+        if (lane < (u32)first) box_merge(b, t);
+    }
+}
 
 // node records without the `parent` word, which the parent's thread writes (collision.cl:119-120)
 struct __attribute__((packed, aligned(4))) LeafTail { u32 right_edge, id; };
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
 
     // inclusive prefix / suffix unions over the chunk (wave shuffles, then the 4 wave totals)
     Box<T> pre = leaf, suf = leaf;
-    if constexpr (DPP_SCAN && sizeof(T) == 4) {          // (every lane of the block is still here: full waves)
+    if constexpr (DPP_SCAN) {          // (every lane of the block is still here: full waves)
         wave_prefix_union(pre);
         wave_suffix_union(suf);
     } else {
@@ -637,10 +682,11 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     const u32 nchunks = L.count[0];
     // mode bit 10 (1024) alone is not a diagnostics mode: it selects the round-3 production instance -- shuffle scans, branchy
     // delta() -- for A/Bs (tools/lbvh_scan_ab.py)
-    if (g_dbg & ~1024)
+    // (bit 11 (2048), likewise: float64 keeps the shuffle scans -- the A/B of the float64 DPP scans)
+    if (g_dbg & ~(1024 | 2048))
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg & ~1024});
-    else if (n < (1u << 30) && sizeof(T) == 4 && !(g_dbg & 1024))
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg & ~(1024 | 2048)});
+    else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))
         k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                                  (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
     else if (n < (1u << 30) && !(g_dbg & 1024))

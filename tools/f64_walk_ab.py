@@ -1,4 +1,5 @@
-"""Whole-path A/B of the float64 asm walk (col_debug_traverse(64) forces the generic loop): python tools/f64_walk_ab.py [n ...]"""
+"""Whole-path A/B of the float64 asm walk (col_debug_traverse(64) forces the generic loop) and of the float64 DPP scans of
+k_chunk (col_debug_lbvh(2048) keeps the shuffle scans): python tools/f64_walk_ab.py [n ...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,8 +16,9 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000]:
             nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
             col = Collider(ctx, n, 64, 256, coord_dtype=dt)
             ref = None
-            for variant in ((64, 0, 64, 0) if dt == "float64" else (0,)):
-                cdll().col_debug_traverse(variant)
+            for variant in ((64, 0, 2048, 0, 2048, 0) if dt == "float64" else (0,)):
+                cdll().col_debug_traverse(64 if variant == 64 else 0)
+                cdll().col_debug_lbvh(2048 if variant == 2048 else 0)
                 def step():
                     col.get_collisions(cq, cb, rb, nb, pb, cap)
                 for _ in range(4): step()
@@ -26,6 +28,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000]:
                 if ref is None: ref = pairs
                 same = pairs.shape == ref.shape and bool((pairs == ref).all())
                 ms = bench.time_events(hip, cq, step, 20)
-                print("n %9d %-8s %s %s: %.4f ms, pairs %d, same set: %s" % (n, name, dt, {64: "generic loop", 0: "asm walk    "}[variant], ms, cnt, same), flush=True)
+                print("n %9d %-8s %s %s: %.4f ms, pairs %d, same set: %s" % (n, name, dt, {64: "generic walk ", 2048: "shuffle scans", 0: "as shipped   "}[variant], ms, cnt, same), flush=True)
             cdll().col_debug_traverse(0)
+            cdll().col_debug_lbvh(0)
             del cb, rb, nb, pb, col
