@@ -83,7 +83,10 @@ __global__ __launch_bounds__(ST) void k_scan_apply(u32 *__restrict__ data, uint6
 // so whichever blocks are resident (other streams or processes may hold part of the GPU) always include
 // one that waits for nothing -- the same assumption every decoupled look-back scan makes.  The epoch
 // makes stale granules from earlier calls invisible without a memset launch.
-constexpr u32 CHAIN_MAX_TILES = 256;      // 4 waves x 64 predecessors
+// Round 4: up to 1024 tiles (the 2 Mi counters of a 64 Mi-pair sort pass: three launches -> one, ~9 us per pass): every thread
+// polls up to CHAIN_PER_THREAD predecessors (tiles t, t + 256, ...), all of its loads in flight together.
+constexpr u32 CHAIN_PER_THREAD = 4;
+constexpr u32 CHAIN_MAX_TILES = ST * CHAIN_PER_THREAD;      // 1024
 __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n, u64 *__restrict__ status, u32 epoch) {
     __shared__ u32 ws[ST / COL_WAVE];
     __shared__ u32 s_prefix;
@@ -98,14 +101,19 @@ __global__ __launch_bounds__(ST) void k_scan_chain(u32 *__restrict__ data, u32 n
     u32 run = block_excl_scan<ST>(t, ws, &total);
     if (threadIdx.x == 0)
         __hip_atomic_store(&status[b], ((u64)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {   // thread t polls predecessor tile t (ST == CHAIN_MAX_TILES); ws is free again after the scan
+    {   // thread t polls predecessor tiles t, t + ST, ... (< b); ws is free again after the scan
         u32 pv = 0;
-        if (threadIdx.x < b) {
-            u64 g;
-            do {
-                g = __hip_atomic_load(&status[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((u32)(g >> 32) != epoch);
-            pv = (u32)g;
+        u64 g[CHAIN_PER_THREAD];
+#pragma unroll
+        for (u32 k = 0; k < CHAIN_PER_THREAD; k++) {       // first look: all of the thread's loads in flight together
+            const u32 t = threadIdx.x + k * ST;
+            g[k] = t < b ? __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)epoch << 32);
+        }
+#pragma unroll
+        for (u32 k = 0; k < CHAIN_PER_THREAD; k++) {       // (b <= ST: only k = 0 ever polls -- the small scans of the 1 M path)
+            const u32 t = threadIdx.x + k * ST;
+            while ((u32)(g[k] >> 32) != epoch) g[k] = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pv += (u32)g[k];
         }
         pv = wave_sum(pv);
         if (lane_id() == 0) ws[threadIdx.x / COL_WAVE] = pv;
