@@ -445,6 +445,25 @@ def test_chunked_pair_allocation_gives_the_same_list(hip_env, oracle, scene, roo
         assert count == oracle.collide(oracle.pad4(coords), radii, capacity=0, want=False)["count"]
 
 
+@pytest.mark.parametrize("room", ["exact", "ample", "tiny"])
+def test_chunked_pair_allocation_float64(hip_env, oracle, room):
+    """Round 4: float64 records have an asm walk of their own (one s_load_dwordx16 per 64-byte record, v_cmpx_*_f64) and
+    with it the chunked pair allocation.  Same contract as for float32, on a dense clustered scene (every workgroup
+    allocates, marked nodes are entered through their leaf chain) and on identical spheres (staging areas overflow)."""
+    for coords, radii in (clustered_scene(60000, 0.01, 0.002, "float64"),
+                          (np.full((2000, 3), 0.25, np.float64), np.full(2000, 0.01, np.float64))):
+        kw = dict(traverse_plan="chunked", group_size=256, ngroups=16)
+        if room == "exact":
+            check_against_oracle(oracle, hip_env, coords, radii, **kw)
+        elif room == "ample":
+            check_against_oracle(oracle, hip_env, coords, radii, extra_capacity=512 * 8192 + 1000, **kw)
+        else:
+            _, _, count, pairs = check_against_oracle(oracle, hip_env, coords, radii, capacity=777, **kw)
+            ref = oracle.collide(oracle.pad4(coords), radii, capacity=max(count, 1))
+            got = pair_set(pairs)
+            assert len(pairs) == min(777, count) == len(got) and got <= pair_set(ref["pairs"])
+
+
 def test_dense_scenes_switch_to_chunked_allocation_on_their_own(hip_env, oracle):
     """"auto": a call publishes the pair count it is about to zero; from DENSE_PAIRS pairs (and with room in the list) the
     calls that follow allocate in chunks.  Exact lists throughout."""
