@@ -80,6 +80,9 @@ _PROTOS = {
     "col_collide_plan_partials": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "col_collide_plan_dev": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "col_collide": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_uint32]),
@@ -97,13 +100,19 @@ _PROTOS = {
     "col_unpack_radii": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
     "col_region_boxes": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_uint32, C.c_int]),
+    "col_region_boxes_dev": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_uint32, C.c_int, C.c_void_p]),
     "col_select_overlap_multi": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]),
+    "col_select_overlap_multi_dev": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "col_pack_slots": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
                               C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "col_ghost_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "col_traverse_ghost_slots": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
+    "col_traverse_ghost_slots_dev": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "col_translate_pairs": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "col_traverse_chunked_scratch_bytes": (C.c_size_t, []),
     "col_traverse_chunked": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,

@@ -385,8 +385,10 @@ template <> struct GhostSel<true> { typedef GhostArgs T; };
 __device__ uint4 g_walk_prof[COL_PROF_PACKETS];
 template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false, bool PROF = false>
 __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
-                                                  const T *__restrict__ bounds, u32 n, u64 *__restrict__ stats,
-                                                  int mode, typename GhostSel<GHOST>::T ghost = {}) {
+                                                  const T *__restrict__ bounds, u32 n_bound, u64 *__restrict__ stats,
+                                                  int mode, typename GhostSel<GHOST>::T ghost = {}, const u32 *__restrict__ n_dev = nullptr) {
+    const u32 n = count_of(n_bound, n_dev);          // device-side count (col_common.h): the grid is sized for the bound
+    if (n_dev && n < (GHOST ? 1u : 2u)) return;     // (the host returns before the launch when it knows the count)
     typedef typename BTypes<T>::V4 V4;
     typedef typename BTypes<T>::Bits Bits;
     __shared__ uint2 s_buf[TW][CAPW];
@@ -1081,7 +1083,7 @@ int g_traverse_variant = 0;       // diagnostics switch, see col_debug_traverse
 
 template <typename T>
 int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                    uint32_t n, uint64_t *stats, int mode, uint32_t *sched = nullptr) {
+                    uint32_t n, uint64_t *stats, int mode, uint32_t *sched = nullptr, const uint32_t *n_dev = nullptr) {
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;               // 2 resident blocks of 16 waves per CU, grid-stride beyond
@@ -1130,9 +1132,9 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     if (sched && !st && !(g_traverse_variant & (16384 | 1 | 2 | 4 | 128 | 1024))) {      // (the other walks are A/B material)
         mode |= 256;
         if ((n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072)) mode |= 512;      // split units
-        if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
-        else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
-        else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode);
+        if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
+        else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
+        else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
         COL_LAUNCH_OK();
         return COL_OK;
     }
@@ -1140,9 +1142,9 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     else if (st) k_traverse<T, true, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (g_traverse_variant & 2) k_traverse<T, false, true, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
     else if (off32 && (g_traverse_variant & 128)) k_traverse<T, false, false, 2><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
-    else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (g_traverse_variant & 1024) ? spread : st, mode);
-    else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode);
+    else if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode, NoGhost{}, n_dev);
+    else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (g_traverse_variant & 1024) ? spread : st, mode, NoGhost{}, n_dev);
+    else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, st, mode, NoGhost{}, n_dev);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -1248,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, 
 // (the list could then not be closed and is rebuilt the exact way: still min(count, capacity) valid pairs).
 template <typename T>
 int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                            uint32_t n, void *scratch) {
+                            uint32_t n, void *scratch, const uint32_t *n_dev = nullptr) {
     // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
     const bool split = (n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072);
     const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256);
@@ -1260,12 +1262,12 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
     const T *bd = (const T *)bounds;
     ChunkHdr *hdr = (ChunkHdr *)scratch;
     COL_HIP(hipMemsetAsync(hdr, 0, 64, s));
-    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn);
+    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn, NoGhost{}, n_dev);
     COL_LAUNCH_OK();
     if (capacity) {
         k_pairs_compact<<<dim3(512), dim3(256), 0, s>>>(pairs, hdr, blocks);
         COL_LAUNCH_OK();
-        k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 64);
+        k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 64, NoGhost{}, n_dev);
         COL_LAUNCH_OK();
     }
     return COL_OK;
@@ -1273,7 +1275,7 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
 
 template <typename T>
 int launch_ghost(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds, uint32_t n,
-                 const GhostArgs &ga, uint32_t max_ghosts) {
+                 const GhostArgs &ga, uint32_t max_ghosts, const uint32_t *n_dev) {
     const u32 npackets = (max_ghosts + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;
@@ -1282,8 +1284,8 @@ int launch_ghost(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
     hipStream_t s = col_stream(stream);
     const T *bd = (const T *)bounds;
     const bool off32 = (2ull * n - 1) * 8 * sizeof(T) < (1ull << 32) && !(g_traverse_variant & 64) && ((uintptr_t)bounds & 63) == 0;
-    if (off32) k_traverse<T, false, false, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
-    else k_traverse<T, false, false, 0, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga);
+    if (off32) k_traverse<T, false, false, 1, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga, n_dev);
+    else k_traverse<T, false, false, 0, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, nullptr, 0, ga, n_dev);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -1294,11 +1296,12 @@ int launch_ghost(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capa
 // by col_traverse_ghost_slots (multi.hip).  `count` (device) = the number of sorted ghosts, at most max_ghosts.
 extern "C" int col_traverse_ghost_packets(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                                           uint32_t n, int coord_bytes, const uint32_t *rec, const uint32_t *order,
-                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids) {
+                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids,
+                                          const uint32_t *n_dev) {
     if (n == 0 || max_ghosts == 0) return COL_OK;
     const GhostArgs ga = {rec, order, count, local_gids};
-    if (coord_bytes == 4) return launch_ghost<float>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts);
-    if (coord_bytes == 8) return launch_ghost<double>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts);
+    if (coord_bytes == 4) return launch_ghost<float>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts, n_dev);
+    if (coord_bytes == 8) return launch_ghost<double>(stream, pairs, counter, capacity, bounds, n, ga, max_ghosts, n_dev);
     return COL_EINVAL;
 }
 
@@ -1370,16 +1373,28 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 // 8192 pairs (one atomic on the counter per chunk instead of one per 512 pairs) and a small kernel closes the holes at
 // the end.  *counter must be 0 on entry (the list starts here).  Record arrays below 4 GB and 64-byte aligned (what the
 // asm walks need); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
+static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
+                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev);
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
+    return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, scratch, nullptr);
+}
+static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
+                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev) {
     const bool off32 = (coord_bytes == 4 || coord_bytes == 8) && (2ull * n - 1) * 8 * (unsigned)coord_bytes < (1ull << 32) &&
                        ((uintptr_t)bounds & 63) == 0;                                                // (see launch_traverse)
     if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
-        return col_traverse(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes);
+    {
+        if (n < 2) return COL_OK;
+        if (capacity > 0 && !pairs) return COL_EINVAL;
+        if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, nullptr, n_dev);
+        if (coord_bytes == 8) return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, nullptr, n_dev);
+        return COL_EINVAL;
+    }
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch);      // (round 4: the asm walk has a float64 form)
-    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch);
+    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev);      // (round 4: the asm walk has a float64 form)
+    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev);
 }
 
 // Diagnostics: same traversal, also accumulates stats[0..7] (8 x u64) = phase-2 steps, descents, leaf
@@ -1420,7 +1435,19 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
                               uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
                               uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,
                               int sort_plan, uint32_t *oversize, const void *partials, uint32_t parts) {
+    return col_collide_plan_dev(stream, coords, radii, n, padded, coord_bytes, codes0, codes1, ids0, ids1, nodes, bounds, flags, scratch,
+                                counter, pairs, capacity, sort_plan, oversize, partials, parts, nullptr);
+}
+
+// The whole path with the number of spheres ON THE DEVICE (include/collision_hip.h): n is a host-known bound that sizes grids,
+// scratch and the sort (rows from *n_dev on become pads), every kernel works on min(n, *n_dev).  Needs the bounds partials
+// (col_minmax4_stage1_dev reads the same word).
+int col_collide_plan_dev(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
+                         uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1, col_node *nodes, void *bounds,
+                         uint32_t *flags, void *scratch, uint32_t *counter, uint32_t *pairs, uint32_t capacity,
+                         int sort_plan, uint32_t *oversize, const void *partials, uint32_t parts, const uint32_t *n_dev) {
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
+    if (n_dev && !partials) return COL_EINVAL;
     if (partials && (parts == 0 || parts > COL_MINMAX_PARTS)) return COL_EINVAL;
     if (padded < n || (capacity > 0 && !pairs)) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
@@ -1460,13 +1487,14 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
         }
         if ((rc = col_morton_tile(stream, coords, radii, partials, parts, n, padded, coord_bytes, codes0, ids0, packed,
                                   counter, (uint32_t *)sort_scratch, tile, (uint32_t)col_ceil_div(padded, tile), msd ? 22 : 0,
-                                  publish))) return rc;
-        if (msd) rc = col_radix_sort_msd(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize);
+                                  publish, n_dev))) return rc;
+        if (msd) rc = col_radix_sort_msd_dev(stream, codes0, codes1, ids0, ids1, padded, sort_scratch, oversize, n_dev);
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;
         // the LSD plan was taken where the MSD plan could apply: tell the caller how clustered the codes are (oversize[1])
         if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_bucket_report(stream, codes1, padded, oversize + 1))) return rc;
     } else {
+        if (n_dev) return COL_EINVAL;            // (a forced tile class: diagnostics only)
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
         if ((rc = col_morton_ex(stream, coords, radii, range, n, padded, coord_bytes, codes0, ids0, packed, counter, publish))) return rc;
         if ((rc = col_radix_sort(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0))) return rc;
@@ -1474,11 +1502,11 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
     // the traversal's packet counters (dynamic packet order, k_traverse): cleared by the tree build's last kernel
     // (variant bit 15: from any size, so that the small parity cases of tests/ take this way too)
     uint32_t *sched = (!chunked && (n >= COL_DYNAMIC_PACKETS_FROM || (g_traverse_variant & 32768))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr)) : nullptr;
-    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched))) return rc;
-    if (chunked) return col_traverse_chunked(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr);
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev))) return rc;
+    if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev);
     if (n < 2) return COL_OK;
-    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched);
-    return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched);
+    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev);
+    return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev);
 }
 
 }  // extern "C"

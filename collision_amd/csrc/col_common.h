@@ -26,7 +26,10 @@ extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii
                              uint32_t *zero_word, uint32_t *publish);
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes,
-                           uint32_t *zero8);      // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
+                           uint32_t *zero8,       // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
+                           const uint32_t *n_dev);   // device-side count (see col_morton_tile), or NULL
+extern "C" int col_radix_sort_msd_dev(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
+                                      uint64_t n, void *scratch, uint32_t *oversize, const uint32_t *n_real_dev);   // radix.hip
 
 // col_collide's fused front end for inputs sorted with the 1024-pair tile (fewer launches, same bits):
 //  * col_minmax4_stage1: stage 1 of col_reduce(MINMAX, width 4) only; `parts` partial results of
@@ -46,16 +49,19 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
 extern "C" int col_minmax4_stage1(void *stream, const void *rows, uint64_t n, int coord_bytes, void *partials, uint32_t *parts);
 extern "C" int col_minmax4_stage1_dev(void *stream, const void *rows, const uint32_t *n_dev, uint32_t n_max, int coord_bytes,
                                       void *partials, uint32_t *parts);
+// DEVICE-SIDE COUNT (round 4, the multi-GPU step): `n_dev` (may be NULL) points at a device word that holds the real number
+// of spheres; `n` is then a host-known upper bound that sizes grids and scratch, and every kernel works on min(n, *n_dev).
 extern "C" int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                                uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
                                uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift,
-                               uint32_t *publish);
+                               uint32_t *publish, const uint32_t *n_dev);
 extern "C" int col_radix_sort_ex(void *stream, const void *keys, void *keys_out, const void *vals, void *vals_out,
                                  uint64_t n, int key_bytes, int val_bytes, void *scratch, int copy_back, int have_hist0);
 
 extern "C" int col_traverse_ghost_packets(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
                                           uint32_t n, int coord_bytes, const uint32_t *rec, const uint32_t *order,
-                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids);   // bvh.hip
+                                          const uint32_t *count, uint32_t max_ghosts, const uint32_t *local_gids,
+                                          const uint32_t *n_dev);   // bvh.hip (n_dev: device-side count of the local tree, or NULL)
 extern "C" int col_radix_sort_low_passes(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals,
                                          uint32_t *vals_out, uint64_t n, void *scratch, int passes);      // radix.hip
 extern "C" int col_radix_bucket_report(void *stream, const uint32_t *sorted_codes, uint64_t n, uint32_t *word);   // see radix.hip
@@ -70,6 +76,9 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 __device__ __forceinline__ u32 lane_id() { return __lane_id(); }
+
+// the real count behind a host-known bound (see col_morton_tile): a wave-uniform (scalar) load
+__device__ __forceinline__ u32 count_of(u32 n, const u32 *__restrict__ n_dev) { return n_dev ? min(n, *n_dev) : n; }
 
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ u32 mbcnt(u64 mask) {

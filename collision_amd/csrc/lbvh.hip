@@ -366,8 +366,10 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                                              const T *__restrict__ packed,
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial, u32 *__restrict__ cross,
-                                             T *__restrict__ tab1, u32 n, T block_k, typename ChunkDiag<DIAG>::T diag) {
+                                             T *__restrict__ tab1, u32 n_bound, T block_k, const u32 *__restrict__ n_dev,
+                                             typename ChunkDiag<DIAG>::T diag) {
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
+    const u32 n = count_of(n_bound, n_dev);  // (device-side count, col_common.h: the grid is sized for the bound)
     typedef typename BT<T>::V4 V4;
     __shared__ ChunkLds<T> lds;
     __shared__ u32 s_codes[WIN];
@@ -378,9 +380,14 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     // 0.1744-0.1757 ms, 2 M 0.293-0.296 against 0.298-0.301, 16 M and config 3 unchanged; a clustered scene at 2 M loses
     // 2.5 % (the deep chunks of a cluster all go to one XCD; strips of 16 chunks going round the XCDs avoid that and
     // gain 0.4 % instead of 1.5 %: not taken).  col_debug_lbvh bit 5 restores chunk = blockIdx.
+    // (with a device-side count the grid is sized for the bound: the first `nb` blocks -- dealt round-robin over the XCDs like
+    // all blocks -- share the real chunks, the others leave; with the bound's chunk count in the formula two of eight XCDs sat idle
+    // at a bound of 1.3 n: 70 instead of 51 us)
+    const u32 nb = n_dev ? (n + (u32)C - 1) / (u32)C : gridDim.x;
+    if (blockIdx.x >= nb) return;            // (n == 0 included)
     u32 chunk = blockIdx.x;
     if (!(dbg & 32)) {
-        const u32 q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x & 7u;
+        const u32 q = nb / 8, r = nb % 8, x = blockIdx.x & 7u;
         chunk = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
     }
     const u32 c0 = chunk * C;
@@ -571,7 +578,13 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
 
 // Sparse table over `count` level-0 entries, 256 per group; group totals go to level 0 of `next`.
 template <typename T>
-__global__ __launch_bounds__(C) void k_group(T *__restrict__ tab, u32 count, T *__restrict__ next) {
+__global__ __launch_bounds__(C) void k_group(T *__restrict__ tab, u32 count, T *__restrict__ next, u32 n_bound, const u32 *__restrict__ n_dev,
+                                             int level) {
+    if (n_dev) {                            // device-side count: this level's real number of entries (chunks, groups, ...)
+        u32 c = count_of(n_bound, n_dev);
+        for (int k = 0; k <= level; k++) c = (c + C - 1) / C;
+        count = min(count, c);
+    }
     __shared__ Table<T> t;
     const int tid = threadIdx.x;
     const u32 g = blockIdx.x;
@@ -627,7 +640,8 @@ __device__ __forceinline__ void cross_node(T *__restrict__ bounds, const u32 *__
 template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
                                                const T *__restrict__ partial, const u32 *__restrict__ cross, Tabs tabs, u32 n,
-                                               u32 nchunks, int lin, u32 *__restrict__ zero8) {
+                                               u32 nchunks, int lin, u32 *__restrict__ zero8, const u32 *__restrict__ n_dev) {
+    if (n_dev) { n = count_of(n, n_dev); nchunks = min(nchunks, (n + (u32)C - 1) / (u32)C); }
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (zero8 && t < 8) zero8[t] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
     const u32 chunk = t / CROSS_CAP, slot = t % CROSS_CAP;
@@ -672,7 +686,7 @@ Layout layout(uint32_t n, int coord_bytes) {
 
 template <typename T>
 int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
-        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8) {
+        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
@@ -685,19 +699,19 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     // (bit 11 (2048), likewise: float64 keeps the shuffle scans -- the A/B of the float64 DPP scans)
     if (g_dbg & ~(1024 | 2048))
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                    (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOn{g_dbg & ~(1024 | 2048)});
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOn{g_dbg & ~(1024 | 2048)});
     else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))
         k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                                 (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+                                                                                 (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else if (n < (1u << 30) && !(g_dbg & 1024))
         k_chunk<T, false, int32_t, false, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                                  (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+                                                                                  (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else if (n < (1u << 30))
         k_chunk<T, false, int32_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+                                                                     (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else
         k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                     (T *)tabs.t[0], n, (T)g_block_k, ChunkDiagOff{});
+                                                                     (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     COL_LAUNCH_OK();
     if (nchunks < 2) {                  // every node lives inside the single chunk: no k_cross, so clear the packet counters here
         if (zero8) COL_HIP(hipMemsetAsync(zero8, 0, 8 * sizeof(u32), s));
@@ -707,12 +721,12 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     for (int h = 0; h < 3; h++) {
         if (h > 0 && L.count[h] <= LIN) { lin = h; break; }      // k_cross scans this level's few entries itself
         const u32 groups = (u32)col_ceil_div(L.count[h], C);
-        k_group<T><<<dim3(groups), dim3(C), 0, s>>>((T *)tabs.t[h], L.count[h], h + 1 < 3 ? (T *)tabs.t[h + 1] : nullptr);
+        k_group<T><<<dim3(groups), dim3(C), 0, s>>>((T *)tabs.t[h], L.count[h], h + 1 < 3 ? (T *)tabs.t[h + 1] : nullptr, n, n_dev, h);
         COL_LAUNCH_OK();
         if (groups < 2) break;
     }
     k_cross<T><<<dim3((unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin,
-                                                                                                     zero8);
+                                                                                                     zero8, n_dev);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -728,22 +742,23 @@ size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, co
 
 // `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
 int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
-                const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8) {
+                const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8,
+                const uint32_t *n_dev) {
     if (n == 0) return COL_OK;
     if (n >= 0x80000000u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
         return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
-                          nodes, (float *)bounds, (char *)scratch, n, zero8);
+                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev);
     if (coord_bytes == 8)
         return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
-                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8);
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev);
     return COL_EINVAL;
 }
 
 int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
              col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
-    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr);
+    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -58,11 +58,13 @@ __global__ __launch_bounds__(256) void k_morton(const Vec4<T> *__restrict__ coor
 constexpr int MT_ROWS = 4;
 template <typename T, int NT, int HALVES>
 __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ coords, const T *__restrict__ partials,
-                                                     u32 parts, u32 n, u32 padded, u32 *__restrict__ codes,
+                                                     u32 parts, u32 n_bound, u32 padded, u32 *__restrict__ codes,
                                                      u32 *__restrict__ ids, const T *__restrict__ radii,
                                                      Vec4<T> *__restrict__ packed, u32 *__restrict__ zero_word,
-                                                     u32 *__restrict__ hist0, u32 nblocks, int hist_shift, u32 *publish) {
+                                                     u32 *__restrict__ hist0, u32 nblocks, int hist_shift, u32 *publish,
+                                                     const u32 *__restrict__ n_dev) {
     constexpr int TILE = NT * MT_ROWS * HALVES, NW = NT / 64;
+    const u32 n = count_of(n_bound, n_dev);       // rows from n on are pads (0xFFFFFFFF), whatever the bound
     __shared__ T s_fold[NW][8];
     __shared__ u32 s_hist[256];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -160,17 +162,17 @@ __global__ __launch_bounds__(NT) void k_morton_tile(const Vec4<T> *__restrict__ 
 template <typename T>
 int launch_morton_tile(hipStream_t s, u32 tile, const void *coords, const void *radii, const void *partials, uint32_t parts,
                        uint32_t n, uint32_t padded, uint32_t *codes, uint32_t *ids, void *packed, uint32_t *zero_word,
-                       uint32_t *hist0, uint32_t nblocks, int hist_shift, uint32_t *publish) {
+                       uint32_t *hist0, uint32_t nblocks, int hist_shift, uint32_t *publish, const uint32_t *n_dev) {
     dim3 grid(nblocks);
     if (tile == 1024)
         k_morton_tile<T, 256, 1><<<grid, dim3(256), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                             (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+                                                             (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish, n_dev);
     else if (tile == 4096)
         k_morton_tile<T, 1024, 1><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish, n_dev);
     else
         k_morton_tile<T, 1024, 2><<<grid, dim3(1024), 0, s>>>((const Vec4<T> *)coords, (const T *)partials, parts, n, padded, codes, ids,
-                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish);
+                                                               (const T *)radii, (Vec4<T> *)packed, zero_word, hist0, nblocks, hist_shift, publish, n_dev);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -181,7 +183,8 @@ extern "C" {
 
 int col_morton_tile(void *stream, const void *coords, const void *radii, const void *partials, uint32_t parts,
                     uint32_t n, uint32_t padded, int coord_bytes, uint32_t *codes, uint32_t *ids, void *packed,
-                    uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift, uint32_t *publish) {
+                    uint32_t *zero_word, uint32_t *hist0, uint32_t tile, uint32_t nblocks, int hist_shift, uint32_t *publish,
+                    const uint32_t *n_dev) {
     if (padded < n || parts == 0 || !hist0 || hist_shift < 0 || hist_shift > 24) return COL_EINVAL;
     if (tile != 1024 && tile != 4096 && tile != 8192) return COL_EINVAL;
     if (padded == 0) return COL_OK;
@@ -189,10 +192,10 @@ int col_morton_tile(void *stream, const void *coords, const void *radii, const v
     if (nblocks != (uint32_t)col_ceil_div(padded, tile)) return COL_EINVAL;
     if (coord_bytes == 4)
         return launch_morton_tile<float>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
-                                         zero_word, hist0, nblocks, hist_shift, publish);
+                                         zero_word, hist0, nblocks, hist_shift, publish, n_dev);
     if (coord_bytes == 8)
         return launch_morton_tile<double>(col_stream(stream), tile, coords, radii, partials, parts, n, padded, codes, ids, packed,
-                                          zero_word, hist0, nblocks, hist_shift, publish);
+                                          zero_word, hist0, nblocks, hist_shift, publish, n_dev);
     return COL_EINVAL;
 }
 

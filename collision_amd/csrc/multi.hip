@@ -78,8 +78,10 @@ constexpr int SEL_ROWS = 32;      // at most: rows per thread, one mask bit each
 template <typename T>
 __global__ __launch_bounds__(256) void k_select_multi(const typename MT<T>::V4 *__restrict__ rows, u32 n,
                                                        const typename MT<T>::V4 *__restrict__ boxes, PeerList pl, u32 stride,
-                                                       u32 *__restrict__ lists, u32 *__restrict__ counts, u32 per_thread) {
+                                                       u32 *__restrict__ lists, u32 *__restrict__ counts, u32 per_thread,
+                                                       const u32 *__restrict__ n_dev) {
     typedef typename MT<T>::V4 V4;
+    n = count_of(n, n_dev);                  // device-side count (col_common.h)
     __shared__ u32 s_warp[4];
     __shared__ u32 s_base;
     const u32 tid = threadIdx.x;
@@ -156,9 +158,10 @@ template <typename T>
 __global__ __launch_bounds__(GW * 64) void k_ghost(const typename MT<T>::V4 *__restrict__ rows, u32 n,
                                                    const u32 *__restrict__ local_gids, u32 *__restrict__ pairs,
                                                    u32 *__restrict__ counter, u32 capacity, const u32 *__restrict__ rec,
-                                                   u32 slot, u32 *__restrict__ flags) {
+                                                   u32 slot, u32 *__restrict__ flags, const u32 *__restrict__ n_dev) {
     typedef typename MT<T>::V4 V4;
     typedef typename MT<T>::Bits Bits;
+    n = count_of(n, n_dev);                  // device-side count (col_common.h): the size of the local tree
     __shared__ uint2 s_buf[GW][GCAP];
     const u32 lane = lane_id(), w = threadIdx.x / 64;
     const u32 leaf_start = n - 1;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(GW * 64) void k_ghost(const typename MT<T>::V4 *__r
         atomicMax(&flags[0], len);
         atomicAdd(&flags[1], min(len, slot));
     }
-    if (g < min(len, slot)) {
+    if (g < min(len, slot) && n > 0) {       // (no local tree: the ghosts are counted, nothing is walked)
         const V4 c = rec_load<T>(base + (u64)MT<T>::RW * (1 + g), &gid);
         lx = c.x - c.w; ly = c.y - c.w; lz = c.z - c.w;                // same arithmetic as leafBounds, collision.cl:139-140
         hx = c.x + c.w; hy = c.y + c.w; hz = c.z + c.w;
@@ -359,8 +362,9 @@ __global__ __launch_bounds__(256) void k_range_fold(const typename MT<T>::V4 *__
 constexpr int RG_VALS = 7 * COL_REGION_BOXES;      // per octant: min x, y, z; max x, y, z; max r
 template <typename T>
 __global__ __launch_bounds__(REGION_NT) void k_region_part(const typename MT<T>::V4 *__restrict__ rows, u32 n, const T *__restrict__ range8,
-                                                      T *__restrict__ partials) {
+                                                      T *__restrict__ partials, const u32 *__restrict__ n_dev) {
     typedef typename MT<T>::V4 V4;
+    n = count_of(n, n_dev);                  // device-side count (col_common.h)
     __shared__ T s_part[REGION_NT / 64][RG_VALS];
     const u32 tid = threadIdx.x, lane = lane_id(), w = tid / 64;
     T v[COL_REGION_BOXES][7];
@@ -826,11 +830,16 @@ int col_partition_sample(void *stream, const void *rows, uint32_t n, uint32_t sa
 // global scene range of the repartition, or NULL: one box (octant 0).  Clears zero[0..zero_count).
 int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out, uint32_t *zero,
                      uint32_t zero_count, int coord_bytes) {
+    return col_region_boxes_dev(stream, rows, n, range8, scratch, out, zero, zero_count, coord_bytes, nullptr);
+}
+
+int col_region_boxes_dev(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out, uint32_t *zero,
+                         uint32_t zero_count, int coord_bytes, const uint32_t *n_dev) {
     if (!scratch || zero_count > 256) return COL_EINVAL;
     hipStream_t s = col_stream(stream);
     const unsigned g = range_blocks(n, REGION_NT);
-    COL_BY_COORD((k_region_part<float><<<dim3(g), dim3(REGION_NT), 0, s>>>((const float4 *)rows, n, (const float *)range8, (float *)scratch)),
-                 (k_region_part<double><<<dim3(g), dim3(REGION_NT), 0, s>>>((const double4 *)rows, n, (const double *)range8, (double *)scratch)));
+    COL_BY_COORD((k_region_part<float><<<dim3(g), dim3(REGION_NT), 0, s>>>((const float4 *)rows, n, (const float *)range8, (float *)scratch, n_dev)),
+                 (k_region_part<double><<<dim3(g), dim3(REGION_NT), 0, s>>>((const double4 *)rows, n, (const double *)range8, (double *)scratch, n_dev)));
     COL_LAUNCH_OK();
     COL_BY_COORD((k_region_fold<float><<<dim3(1), dim3(256), 0, s>>>((const float *)scratch, g, (float4 *)out, zero, zero_count)),
                  (k_region_fold<double><<<dim3(1), dim3(256), 0, s>>>((const double *)scratch, g, (double4 *)out, zero, zero_count)));
@@ -915,6 +924,12 @@ int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii, in
 
 int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
                              int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes) {
+    return col_select_overlap_multi_dev(stream, rows, n, boxes, peers, n_peers, stride, lists, counts, coord_bytes, nullptr);
+}
+
+int col_select_overlap_multi_dev(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
+                                 int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes,
+                                 const uint32_t *n_dev) {
     if (n_peers < 0 || n_peers > 8) return COL_EINVAL;
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     if (n == 0 || n_peers == 0) return COL_OK;
@@ -927,8 +942,8 @@ int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const v
     if (per_thread < 1) per_thread = 1;
     if (per_thread > (u32)SEL_ROWS) per_thread = SEL_ROWS;
     const unsigned sel_blocks = (unsigned)col_ceil_div(n, 256ull * per_thread);
-    COL_BY_COORD((k_select_multi<float><<<dim3(sel_blocks), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts, per_thread)),
-                 (k_select_multi<double><<<dim3(sel_blocks), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts, per_thread)));
+    COL_BY_COORD((k_select_multi<float><<<dim3(sel_blocks), dim3(256), 0, s>>>((const float4 *)rows, n, (const float4 *)boxes, pl, stride, lists, counts, per_thread, n_dev)),
+                 (k_select_multi<double><<<dim3(sel_blocks), dim3(256), 0, s>>>((const double4 *)rows, n, (const double4 *)boxes, pl, stride, lists, counts, per_thread, n_dev)));
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -958,6 +973,13 @@ size_t col_ghost_scratch_bytes(uint32_t n_slots, uint32_t slot_records) {
 int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
                              uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
                              uint32_t *flags, int coord_bytes, void *scratch) {
+    return col_traverse_ghost_slots_dev(stream, rec, n_slots, slot_records, bounds, n, local_gids, pairs, counter, capacity, flags,
+                                        coord_bytes, scratch, nullptr);
+}
+
+int col_traverse_ghost_slots_dev(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
+                                 uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter, uint32_t capacity,
+                                 uint32_t *flags, int coord_bytes, void *scratch, const uint32_t *n_dev) {
     if (coord_bytes != 4 && coord_bytes != 8) return COL_EINVAL;
     if (n_slots == 0 || slot_records == 0 || n == 0) return COL_OK;
     if ((capacity > 0 && !pairs) || !flags) return COL_EINVAL;
@@ -975,11 +997,11 @@ int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, ui
         int rc = col_radix_sort_low_passes(stream, keys0, keys1, vals0, vals1, e, sort_scratch, 2);
         if (rc) return rc;
         return col_traverse_ghost_packets(stream, pairs, counter, capacity, bounds, n, coord_bytes, (const u32 *)rec, vals1,
-                                          flags + 1, (uint32_t)e, local_gids);
+                                          flags + 1, (uint32_t)e, local_gids, n_dev);
     }
     dim3 grid((unsigned)col_ceil_div(slot_records, GW * 64), n_slots), block(GW * 64);
-    COL_BY_COORD((k_ghost<float><<<grid, block, 0, s>>>((const float4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags)),
-                 (k_ghost<double><<<grid, block, 0, s>>>((const double4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags)));
+    COL_BY_COORD((k_ghost<float><<<grid, block, 0, s>>>((const float4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags, n_dev)),
+                 (k_ghost<double><<<grid, block, 0, s>>>((const double4 *)bounds, n, local_gids, pairs, counter, capacity, (const u32 *)rec, slot_records, flags, n_dev)));
     COL_LAUNCH_OK();
     return COL_OK;
 }

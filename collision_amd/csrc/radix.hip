@@ -606,7 +606,7 @@ __device__ __forceinline__ void bucket_rank(BucketLds<BS_IT> &lds, const u32 (&k
 template <int BS_IT>
 __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u32 *__restrict__ v_a, u32 *__restrict__ k_b,
                                                         u32 *__restrict__ v_b, u32 n, const u32 *__restrict__ offsets,
-                                                        u32 nblocks, u32 *oversize) {
+                                                        u32 nblocks, u32 *oversize, const u32 *__restrict__ n_real_dev) {
     constexpr u32 BS_CAP = BS_NT * BS_IT;
     constexpr int BS_ROW = COL_WAVE * BS_IT;       // positions per wave
     __shared__ BucketLds<BS_IT> lds;
@@ -614,7 +614,21 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort(u32 *__restrict__ k_a, u3
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid / COL_WAVE));
     const u32 d = blockIdx.x;
     const u32 start = offsets[(uint64_t)d * nblocks], end = d + 1 < RDIG ? offsets[(uint64_t)(d + 1) * nblocks] : n;
-    const u32 S = end - start;
+    // DEVICE-SIDE COUNT (col_common.h): of the n pairs only the first *n_real_dev are real codes, the rest are pads
+    // (0xFFFFFFFF) -- possibly far more than a bucket holds when n is a capacity.  They sit at the END of bucket 255 in the order
+    // of their ids (the global pass is stable and they came last), i.e. sorted position j >= n_real holds the pad with id j:
+    // bucket 255 sorts its real codes only, and every workgroup writes its 256th of the pads (one workgroup copying 3 * 10^5
+    // of them through cost the one-rank step 0.14 ms).
+    u32 pads = 0;
+    if (n_real_dev) {
+        const u32 n_real = min(n, *n_real_dev), all = n - n_real, per = (all + RDIG - 1) / RDIG;
+        for (u32 i = threadIdx.x; i < per; i += BS_NT) {
+            const u32 j = n_real + d * per + i;
+            if (j < n) { k_b[j] = 0xFFFFFFFFu; v_b[j] = j; }
+        }
+        if (d == RDIG - 1) pads = min(end - start, all);
+    }
+    const u32 S = end - start - pads;
     if (S == 0) return;
     u32 key[BS_IT], val[BS_IT], pos[BS_IT];
 
@@ -1138,6 +1152,12 @@ __global__ __launch_bounds__(RDIG) void k_bucket_report(const u32 *__restrict__ 
 // that did not fit LDS, if any.
 int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
                        uint64_t n, void *scratch, uint32_t *oversize) {
+    return col_radix_sort_msd_dev(stream, keys, keys_out, vals, vals_out, n, scratch, oversize, nullptr);
+}
+
+// ... with the number of real codes on the device (pads beyond it: see k_bucket_sort); internal (col_common.h)
+int col_radix_sort_msd_dev(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
+                           uint64_t n, void *scratch, uint32_t *oversize, const uint32_t *n_real_dev) {
     if (n == 0) return COL_OK;
     if (!scratch || !vals || !vals_out) return COL_EINVAL;
     if (n > COL_MSD_MAX_N) return COL_EINVAL;
@@ -1156,9 +1176,9 @@ int col_radix_sort_msd(void *stream, const uint32_t *keys, uint32_t *keys_out, c
     if (rc) return rc;
     // a uniform scene puts n / 256 codes into a bucket: the 8192-pair finish up to ~1.9 M, the 16384-pair one above
     if (n <= COL_MSD_SMALL_N)
-        k_bucket_sort<8><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+        k_bucket_sort<8><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize, n_real_dev);
     else
-        k_bucket_sort<16><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize);
+        k_bucket_sort<16><<<dim3(RDIG), dim3(BS_NT), 0, s>>>(tmp_keys, tmp_vals, keys_out, vals_out, (u32)n, hist, (u32)nb, oversize, n_real_dev);
     COL_LAUNCH_OK();
     return COL_OK;
 }

@@ -346,6 +346,15 @@ class HipEngine(ProtocolOps):
         self._bounds_parts = C.c_uint32(0)
         self._have_partials = False
         self._early_partials = not os.environ.get("COLLISION_NO_EARLY_PARTIALS")
+        # DEVICE-SIDE OWNED COUNT (round 4): after a repartition every launch that needs the number of owned spheres reads it
+        # from the device word the unpack leaves (owned2[0] = min(m, capacity)) with the rank capacity as its host-known bound
+        # (col_collide_plan_dev and the *_dev entry points of include/collision_hip.h), so a step is enqueue-only: the host
+        # never waits for m.  owned_count() reads the same number from the host-visible word when somebody asks for it
+        # (synchronize(), adopt_owned(), tests).  COLLISION_HOST_OWNED_COUNT=1: the round-3 behaviour, a poll inside the step.
+        self.device_count = self._early_partials and not os.environ.get("COLLISION_HOST_OWNED_COUNT")
+        # the bound the device-count launches are sized for: the rank capacity at first, then a few per cent above the counts
+        # seen (DistributedCollider.synchronize(): a bound of 1.3 n sorts 30 % pads and takes the next tile class)
+        self.run_bound = capacity
         word = C.c_void_p()
         call.col_host_alloc(C.byref(word), 64)
         self._host_word = word.value                           # host-visible: (step number << 32 | owned count)
@@ -462,10 +471,21 @@ class HipEngine(ProtocolOps):
         """Single-GPU path on the owned spheres; pairs come out as global ids."""
         s = self.cq.stream
         self.n_owned = n
+        c, p = self.collider, self._p
+        if n is None:                             # the count is on the device (owned2[0]): the rank capacity is the bound
+            if not (rows is self.owned_rows and self._have_partials):
+                raise RuntimeError("a device-side owned count needs the repartition's early bounds partials")
+            self._have_partials = False
+            call.col_collide_plan_dev(s, rows.data_ptr(), p["radii"], self.run_bound, roundUp(self.run_bound, 2 * self.group_size), self.cb,
+                                      c._codes_bufs[0].ptr, c._codes_bufs[1].ptr, c._ids_bufs[0].ptr, c._ids_bufs[1].ptr,
+                                      c._nodes_buf.ptr, c._bounds_buf.ptr, None, c._alloc["scratch"].ptr,
+                                      p["counter"], p["pairs"], self.pair_capacity, c._choose_plan(self.pair_capacity), c._plan_word,
+                                      p["_bounds_partials"], self._bounds_parts.value, p["owned2"])
+            call.col_translate_pairs(s, p["pairs"], p["counter"], 0, self.pair_capacity, gids.data_ptr())
+            return
         if n == 0:
             self.counter.zero_()
             return                                # (col_collide zeroes the counter itself)
-        c, p = self.collider, self._p
         if rows is not self.owned_rows:           # owned rows come out of the repartition with radii already split off
             call.col_unpack_radii(s, rows.data_ptr(), n, p["radii"], self.cb)
         partials = p["_bounds_partials"] if (rows is self.owned_rows and self._have_partials) else None
@@ -481,6 +501,10 @@ class HipEngine(ProtocolOps):
     def region_boxes(self, rows, n, repartitioned):
         """One launch; also clears the halo list counters."""
         p = self._p
+        if n is None:                             # (device-side owned count: see __init__)
+            call.col_region_boxes_dev(self.cq_side.stream, rows.data_ptr(), self.run_bound, p["grange8"] if repartitioned else None,
+                                      p["_range_scratch_side"], p["boxes"], p["sel_counts"], MAX_PEERS, self.cb, p["owned2"])
+            return self.boxes
         call.col_region_boxes(self.cq_side.stream, rows.data_ptr(), n, p["grange8"] if repartitioned else None,
                               p["_range_scratch_side"], p["boxes"], p["sel_counts"], MAX_PEERS, self.cb)
         return self.boxes
@@ -500,8 +524,13 @@ class HipEngine(ProtocolOps):
             return
         s, p = self.cq_side.stream, self._p
         arr = (C.c_int * len(peers))(*peers)
-        call.col_select_overlap_multi(s, rows.data_ptr(), n, boxes_dev.data_ptr(), arr, len(peers),
-                                      self.capacity, p["sel_lists"], p["sel_counts"], self.cb)
+        if n is None:                             # (device-side owned count: see __init__)
+            call.col_select_overlap_multi_dev(s, rows.data_ptr(), self.run_bound, boxes_dev.data_ptr(), arr, len(peers),
+                                              self.capacity, p["sel_lists"], p["sel_counts"], self.cb, p["owned2"])
+            n = self.run_bound
+        else:
+            call.col_select_overlap_multi(s, rows.data_ptr(), n, boxes_dev.data_ptr(), arr, len(peers),
+                                          self.capacity, p["sel_lists"], p["sel_counts"], self.cb)
         call.col_pack_slots(s, rows.data_ptr(), gids.data_ptr(), p["sel_lists"], self.capacity,
                             p["sel_counts"], len(peers), min(max(n, 1), slot), self.halo_send.data_ptr(),
                             int(self.halo_send.shape[0]), slot, self.cb)
@@ -517,6 +546,7 @@ class HipEngine(ProtocolOps):
         if self.n_owned == 0 or n_in == 0:
             return
         p = self._p
+        dev = self.n_owned is None                # (device-side owned count: see __init__)
         scratch = None
         want_packets = os.environ.get("COLLISION_GHOST_WALK", "auto")
         if want_packets == "packets" or (want_packets == "auto" and (expected is None or expected >= self.GHOST_PACKETS_FROM)
@@ -529,6 +559,11 @@ class HipEngine(ProtocolOps):
                 with self.torch.cuda.stream(self.main):
                     self._ghost_scratch = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
             scratch = self._ghost_scratch.data_ptr()
+        if dev:
+            call.col_traverse_ghost_slots_dev(self.cq.stream, self.halo_recv.data_ptr(), n_in, slot,
+                                              self.collider._bounds_buf.ptr, self.run_bound, owned_gids.data_ptr(),
+                                              p["pairs"], p["counter"], self.pair_capacity, p["flags"], self.cb, scratch, p["owned2"])
+            return
         call.col_traverse_ghost_slots(self.cq.stream, self.halo_recv.data_ptr(), n_in, slot,
                                       self.collider._bounds_buf.ptr, self.n_owned, owned_gids.data_ptr(),
                                       p["pairs"], p["counter"], self.pair_capacity, p["flags"], self.cb, scratch)
@@ -630,6 +665,26 @@ class DistributedCollider:
         self.own_rows = self.own_gids = None
         self.n_owned = 0
 
+    @property
+    def n_owned(self):
+        """Spheres this rank owns after the last step.  With a device-side count (HipEngine.device_count) step() does not know
+        it: the first reader takes it from the host-visible word the repartition's unpack wrote (a poll that returns at once
+        when the step has run -- synchronize() asks -- and otherwise waits for the unpack, nothing more)."""
+        if self._n_owned is None:
+            m = self.engine.owned_count()
+            if m > self.capacity:
+                raise RuntimeError("rank %d would own %d spheres > capacity %d" % (self.rank, m, self.capacity))
+            self._n_owned = m
+            self.engine.n_owned = m
+        self.stats["owned"] = self._n_owned
+        return self._n_owned
+
+    @n_owned.setter
+    def n_owned(self, m):
+        self._n_owned = m
+        if m is not None:
+            self.stats["owned"] = m
+
     def set_local_spheres(self, coords4, radii, gids):
         self.n_in = self.engine.load(coords4, radii, gids)
 
@@ -704,13 +759,15 @@ class DistributedCollider:
             e.partition_unpack(R, r, pslot)
             e.mark_fork()
             own_rows, own_gids = e.owned_rows, e.owned_gids
-            m = e.owned_count()                                        # the step's one host wait
-            if m > self.capacity:
-                raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
+            if getattr(e, "device_count", False):
+                m = None                                               # on the device; the host reads it when asked (n_owned)
+            else:
+                m = e.owned_count()                                    # (engines without it: the step's one host wait)
+                if m > self.capacity:
+                    raise RuntimeError("rank %d would own %d spheres > capacity %d" % (r, m, self.capacity))
         else:
             e.mark_fork()
             own_rows, own_gids, m = rows, gids, n
-        self.stats["owned"] = m
         self.own_rows, self.own_gids, self.n_owned = own_rows, own_gids, m      # (tests read these back)
 
         # 3a. the single-GPU path on the owned spheres, enqueued first: the device works on it while the host
@@ -744,13 +801,23 @@ class DistributedCollider:
     def _sync_gen(self):
         e = self.engine
         e.synchronize()
+        _ = self.n_owned                     # (a device-side owned count becomes known to the host here)
         if not self._dirty or not (self.world > 1 or self.exercise):
             self._dirty = False
             return
         cap = roundUp(self.capacity, 1024)
         while True:
             longest, ghosts, longest_part = e.halo_stats()
-            longest, longest_part = yield ("all_reduce", "main", [longest, longest_part], "max")
+            # (device-side owned count: a rank that owns more than the bound its launches were sized for worked on the first
+            # `bound` of its spheres only -- every rank repeats the step with the bound raised, like a halo slot that overflowed)
+            bound_over = 0
+            if getattr(e, "device_count", False) and self.partition == "morton":
+                m, bound = self.n_owned, e.run_bound
+                bound_over = 1 if m > bound else 0
+                want_b = min(self.capacity, roundUp(m + m // 32 + 2048, 2 * e.group_size))
+                if m > bound or want_b > bound or 10 * want_b < 9 * bound:
+                    e.run_bound = want_b
+            longest, longest_part, bound_over = yield ("all_reduce", "main", [longest, longest_part, bound_over], "max")
             # (both are all-reduced: every rank takes the same decisions below and leaves together)
             if max(longest, longest_part) > cap:     # (cannot happen: a list is a subset of what one rank holds)
                 raise RuntimeError("a list of %d records cannot fit any slot (rank capacity %d)"
@@ -765,7 +832,7 @@ class DistributedCollider:
                 self.stats["partition_overflows"] += 1
             elif 20 * want_p <= 17 * self.part_slot:        # (shrink with hysteresis: lists that breathe by a few % keep their slot)
                 self.part_slot = want_p
-            again = False
+            again = bool(bound_over)
             if longest > self.slot:
                 self.slot, again = min(want, cap), True
             elif self.partition != "hash" and (want < self.slot // 2 or want > self.slot):

@@ -269,6 +269,17 @@ int col_collide_plan_partials(void *stream, const void *coords, const void *radi
                               col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,
                               uint32_t *collisions, uint32_t capacity, int sort_plan, uint32_t *oversize,
                               const void *partials, uint32_t parts);
+/* The same call with the NUMBER OF SPHERES ON THE DEVICE (round 4: the multi-GPU step, where a rank learns how many spheres it
+ * owns from an exchange the host does not wait for).  *n_dev (device memory, written by earlier work on the stream) holds the
+ * real count; n is a host-known upper bound -- the capacity of the arrays -- that sizes grids, scratch and the sort:
+ * rows from *n_dev on are sorted as pads and every kernel works on min(n, *n_dev) spheres.  Outputs exactly those of
+ * col_collide_plan_partials(n = *n_dev) for the first *n_dev sorted entries, all 2 * (*n_dev) - 1 nodes and boxes and the
+ * pair list.  `partials` is required (col_minmax4_stage1_dev with the same word).  n_dev == NULL: as above. */
+int col_collide_plan_dev(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded_size,
+                         int coord_bytes, uint32_t *codes0, uint32_t *codes1, uint32_t *ids0, uint32_t *ids1,
+                         col_node *nodes, void *bounds, uint32_t *flags, void *scratch, uint32_t *n_collisions,
+                         uint32_t *collisions, uint32_t capacity, int sort_plan, uint32_t *oversize,
+                         const void *partials, uint32_t parts, const uint32_t *n_dev);
 
 /* ---------------------------------------------------------------- multi-GPU helpers
  * New work (the reference is single-device): device side of the sphere
@@ -321,11 +332,17 @@ int col_unpack_radii(void *stream, const void *rows, uint32_t n, void *radii, in
  * buffer when the two run on different streams); also clears zero[0 .. zero_count) (the halo list counters). */
 int col_region_boxes(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out,
                      uint32_t *zero, uint32_t zero_count, int coord_bytes);
+int col_region_boxes_dev(void *stream, const void *rows, uint32_t n, const void *range8, void *scratch, void *out,
+                     uint32_t *zero, uint32_t zero_count, int coord_bytes,
+        const uint32_t *n_dev);   /* ... with the row / tree count on the device: n is a bound, see col_collide_plan_dev */
 /* halo selection in one launch: boxes = DEVICE array [world][8 boxes][8] (lo.xyz,-,hi.xyz,-) as produced by
  * the AABB all-gather of every rank's col_region_boxes; peers = HOST array of n_peers <= 8 rank numbers; lists[k*stride ...] and
  * counts[k] (zeroed beforehand: col_region_boxes does it) receive the spheres overlapping any box of peers[k] */
 int col_select_overlap_multi(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
                              int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes);
+int col_select_overlap_multi_dev(void *stream, const void *rows, uint32_t n, const void *boxes, const int *peers,
+                             int n_peers, uint32_t stride, uint32_t *lists, uint32_t *counts, int coord_bytes,
+        const uint32_t *n_dev);   /* ... with the row / tree count on the device: n is a bound, see col_collide_plan_dev */
 /* the n_lists lists as fixed SLOTS of 1 + slot_records records each: a header record (first word = the list's
  * full length) followed by min(length, slot_records) records; list sizes are read on the device.  A fixed-size
  * exchange of such slots needs no count exchange and no host sync; the receiver learns the lengths -- and an
@@ -344,6 +361,10 @@ size_t col_ghost_scratch_bytes(uint32_t n_slots, uint32_t slot_records);
 int col_traverse_ghost_slots(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
                              uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter,
                              uint32_t capacity, uint32_t *flags, int coord_bytes, void *scratch);
+int col_traverse_ghost_slots_dev(void *stream, const void *rec, uint32_t n_slots, uint32_t slot_records, const void *bounds,
+                             uint32_t n, const uint32_t *local_gids, uint32_t *pairs, uint32_t *counter,
+                             uint32_t capacity, uint32_t *flags, int coord_bytes, void *scratch,
+        const uint32_t *n_dev);   /* ... with the row / tree count on the device: n is a bound, see col_collide_plan_dev */
 /* pairs[first .. min(*count, capacity)) : index -> gids[index] */
 int col_translate_pairs(void *stream, uint32_t *pairs, const uint32_t *count, uint32_t first,
                         uint32_t capacity, const uint32_t *gids);

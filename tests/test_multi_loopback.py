@@ -132,3 +132,54 @@ def test_config4_world8_two_million_per_rank(hip_env, oracle, partition):
     cnt, ref = run_collider(ctx, cq, Collider(ctx, n, 64, 256), coords, radii, 1 << 21)
     assert cnt <= 1 << 21 and cnt == len(got)
     np.testing.assert_array_equal(got, _undirected(ref))
+
+
+@pytest.mark.gpu
+def test_a_step_never_waits_for_the_owned_count(hip_env, oracle):
+    """Round 4: after the repartition every launch reads the number of owned spheres from the device word the unpack leaves
+    (col_collide_plan_dev and the *_dev halo entry points), so step() only enqueues: the host-visible word is not looked at
+    before synchronize() / n_owned.  Four ranks with real HIP engines on the one GPU, Morton repartition; the owned counts
+    differ from rank to rank and from the capacity; pairs == brute force, per-rank arrays == the oracle on what a rank owns."""
+    from collision_amd.multi import HipEngine
+    from tests.dist_worker import per_rank_parity, scene
+    ctx, _ = hip_env
+    world, n = 4, 30000
+    coords, radii = scene(n, world, "clustered")
+    gids = np.arange(n, dtype=np.uint32)
+    owner = hash_owner(gids, world)
+    lw = LoopbackWorld(ctx, world, [int((owner == r).sum()) for r in range(world)], group_size=64,
+                       pair_capacity=1 << 20, partition="morton")
+    assert all(dc.engine.device_count for dc in lw.ranks)
+    _load(lw, coords, radii, world)
+    polls = []
+    real = HipEngine.owned_count
+    HipEngine.owned_count = lambda self: polls.append(1) or real(self)
+    try:
+        lw.step()
+        lw.step()
+        assert polls == []                      # two steps enqueued, nobody asked
+        pairs = lw.pairs()                      # synchronize(): now the counts are read
+        assert len(polls) >= world
+    finally:
+        HipEngine.owned_count = real
+    owned = [dc.n_owned for dc in lw.ranks]
+    assert sum(owned) == n and len(set(owned)) > 1 and all(m < dc.capacity for m, dc in zip(owned, lw.ranks))
+    for dc in lw.ranks:
+        assert per_rank_parity(dc) == "ok"
+    cnt, ref = oracle.brute_force(coords, radii)
+    got = _undirected(np.concatenate(pairs))
+    assert len(got) == cnt and (np.diff(got) != 0).all()
+    np.testing.assert_array_equal(got, _undirected(ref))
+    # the launches of a step are sized for a bound a few per cent above the counts seen; a rank that comes to own more works on
+    # the first `bound` of its spheres only, which synchronize() sees (all ranks repeat the step with the bound raised)
+    assert all(dc.engine.run_bound < dc.capacity and dc.engine.run_bound >= dc.n_owned for dc in lw.ranks)
+    repeats = [dc.repeats for dc in lw.ranks]
+    lw.ranks[1].engine.run_bound = 512                  # far too small
+    lw.ranks[2].engine.run_bound = lw.ranks[2].n_owned - 1
+    lw.step()
+    got = _undirected(np.concatenate(lw.pairs()))
+    np.testing.assert_array_equal(got, _undirected(ref))
+    assert all(dc.repeats == r0 + 1 for dc, r0 in zip(lw.ranks, repeats))
+    assert all(dc.engine.run_bound >= dc.n_owned for dc in lw.ranks)
+    for dc in lw.ranks:
+        assert per_rank_parity(dc) == "ok"

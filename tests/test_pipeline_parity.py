@@ -528,3 +528,63 @@ def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene):
                 assert_same_pair_set(pairs, ref["pairs"])
     finally:
         lib.col_debug_traverse(0)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("scene,n,bound,plan", [("uniform", 50000, 65000, 1), ("uniform", 50000, 50000, 1), ("uniform", 700000, 912000, 1),
+                                                 ("uniform", 700000, 912000, 0), ("clustered", 60000, 100000, 1), ("uniform", 300, 70000, 1),
+                                                 ("uniform", 1, 5000, 1), ("uniform", 0, 5000, 1), ("dense", 20000, 26000, 3)])
+def test_count_on_the_device_gives_the_same_arrays(hip_env, oracle, dtype, scene, n, bound, plan):
+    """col_collide_plan_dev (round 4: the multi-GPU step does not wait for its owned count): the number of spheres lives in a
+    device word, the host passes a BOUND (the capacity of the arrays) that sizes grids, scratch and the sort.  The first n
+    sorted codes / ids, all 2 n - 1 nodes and boxes and the pair set must be those of the oracle on the n spheres -- with
+    the MSD plan (the pads beyond n sit behind bucket 255's real codes and are copied through), the LSD plan, chunked pair
+    allocation, a bound equal to n, and n = 0 / 1 (no tree)."""
+    import ctypes as C
+    from collision_amd import hip
+    from collision_amd._lib import call
+    from collision_amd.collision import Node
+    from tests.util import download, upload
+    ctx, cq = hip_env
+    if scene == "clustered":
+        coords, radii = clustered_scene(n, 0.01, 0.002, dtype)
+    elif scene == "dense":
+        coords, radii = clustered_scene(n, 0.004, 0.002, dtype)
+    else:
+        coords, radii = uniform_scene(max(n, 1), 0.5 * max(n, 1) ** (-1.0 / 3.0), dtype)
+        coords, radii = coords[:n], radii[:n]
+    gs, cb = 256, np.dtype(dtype).itemsize
+    col = Collider(ctx, bound, 16, gs, dtype)
+    col._allocate()
+    rows = np.zeros((bound, 4), dtype)
+    rows[:n, :3] = coords
+    rows[n:] = 7.0                                   # rows beyond the count: never read as spheres
+    rad = np.full(bound, 3.0, dtype)
+    rad[:n] = radii
+    rb, qb = upload(ctx, rows), upload(ctx, rad)
+    cap = 1 << 22
+    nb, pb, word = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8), upload(ctx, np.array([n, n], np.uint32))
+    partials, parts = hip.Buffer(ctx, 256 * 8 * cb), C.c_uint32(0)
+    call.col_minmax4_stage1_dev(cq.stream, rb.ptr, word.ptr, bound, cb, partials.ptr, C.byref(parts))
+    call.col_collide_plan_dev(cq.stream, rb.ptr, qb.ptr, bound, col.padded_size, cb, col._codes_bufs[0].ptr, col._codes_bufs[1].ptr,
+                              col._ids_bufs[0].ptr, col._ids_bufs[1].ptr, col._nodes_buf.ptr, col._bounds_buf.ptr, None,
+                              col._alloc["scratch"].ptr, nb.ptr, pb.ptr, cap, plan, None, partials.ptr, parts.value, word.ptr)
+    cq.finish()
+    count = int(download(cq, nb, np.uint32, 1)[0])
+    if n < 2:
+        assert count == 0
+        return
+    ref = oracle.collide(oracle.pad4(coords), radii, padded=-(-n // (2 * gs)) * (2 * gs), capacity=cap)
+    assert count == ref["count"]
+    codes, ids = download(cq, col._codes_bufs[1], np.uint32, col.padded_size), download(cq, col._ids_bufs[1], np.uint32, col.padded_size)
+    np.testing.assert_array_equal(codes[:n], ref["codes"][:n])
+    np.testing.assert_array_equal(ids[:n], ref["ids"][:n])
+    assert (codes[n:] == 0xFFFFFFFF).all() and (np.sort(ids[n:]) == np.arange(n, col.padded_size)).all()       # the pads, each once
+    nodes = download(cq, col._nodes_buf, Node, 2 * n - 1)
+    bounds = download(cq, col._bounds_buf, dtype, (2 * n - 1, 2, 4))
+    np.testing.assert_array_equal(nodes["right_edge"], ref["nodes"]["right_edge"])
+    np.testing.assert_array_equal(nodes["parent"][1:], ref["nodes"]["parent"][1:])
+    np.testing.assert_array_equal(nodes["data"][:n - 1], ref["nodes"]["data"][:n - 1])
+    np.testing.assert_array_equal(nodes["data"][n - 1:, 0], ref["nodes"]["data"][n - 1:, 0])
+    np.testing.assert_array_equal(bounds[:, :, :3], ref["bounds"][:, :, :3])
+    assert_same_pair_set(download(cq, pb, np.uint32, (count, 2)), ref["pairs"])
