@@ -386,7 +386,8 @@ __device__ uint4 g_walk_prof[COL_PROF_PACKETS];
 template <typename T, bool STATS, bool VEC, int WALK, bool GHOST = false, bool PROF = false>
 __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_traverse(u32 *__restrict__ pairs, u32 *__restrict__ counter, u32 capacity,
                                                   const T *__restrict__ bounds, u32 n_bound, u64 *__restrict__ stats,
-                                                  int mode, typename GhostSel<GHOST>::T ghost = {}, const u32 *__restrict__ n_dev = nullptr) {
+                                                  int mode, typename GhostSel<GHOST>::T ghost = {}, const u32 *__restrict__ n_dev = nullptr,
+                                                  u32 *__restrict__ walk_order = nullptr) {
     const u32 n = count_of(n_bound, n_dev);          // device-side count (col_common.h): the grid is sized for the bound
     if (n_dev && n < (GHOST ? 1u : 2u)) return;     // (the host returns before the launch when it knows the count)
     typedef typename BTypes<T>::V4 V4;
@@ -492,6 +493,10 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
             only2 = !only1;
             if (only1) packet -= p_end - p_lo;
         }
+        // WALK ORDER (col_common.h): walk unit u of the dynamic order is packet perm[u] -- the XCD's packets, longest walk of the
+        // previous call first; the walk's time goes into cost[] for the next call
+        const bool ordered = !STATS && !GHOST && dyn && walk_order != nullptr && !only1;
+        if (ordered) packet = (u32)__builtin_amdgcn_readfirstlane((int)walk_order[(n_bound + 63u) / 64u + packet]);
         const u32 q0 = packet * 64, q = q0 + lane;
         u64 prof_t0 = 0, prof_t1 = 0, prof_t2 = 0;
         if constexpr (PROF) prof_t0 = wall_clock64();
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
         if ((mode & 2) || only1) idx = END;
+        const u64 walk_t0 = ordered ? __builtin_amdgcn_s_memtime() : 0ull;
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
@@ -948,6 +954,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                 idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
         }
+        if (ordered && lane == 0) walk_order[packet] = (u32)min(__builtin_amdgcn_s_memtime() - walk_t0, 0xFFFFFFFFull);
         if constexpr (PROF) {
             const u64 prof_t3 = wall_clock64();
             if (lane == 0 && packet < COL_PROF_PACKETS && !only1)
@@ -1083,7 +1090,8 @@ int g_traverse_variant = 0;       // diagnostics switch, see col_debug_traverse
 
 template <typename T>
 int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                    uint32_t n, uint64_t *stats, int mode, uint32_t *sched = nullptr, const uint32_t *n_dev = nullptr) {
+                    uint32_t n, uint64_t *stats, int mode, uint32_t *sched = nullptr, const uint32_t *n_dev = nullptr,
+                    uint32_t *walk_order = nullptr) {
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;               // 2 resident blocks of 16 waves per CU, grid-stride beyond
@@ -1132,9 +1140,9 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     if (sched && !st && !(g_traverse_variant & (16384 | 1 | 2 | 4 | 128 | 1024))) {      // (the other walks are A/B material)
         mode |= 256;
         if ((n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072)) mode |= 512;      // split units
-        if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
-        else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
-        else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev);
+        if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev, (g_traverse_variant & 2097152) ? nullptr : walk_order);
+        else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev, (g_traverse_variant & 2097152) ? nullptr : walk_order);
+        else k_traverse<T, false, false, 0><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev, (g_traverse_variant & 2097152) ? nullptr : walk_order);
         COL_LAUNCH_OK();
         return COL_OK;
     }
@@ -1250,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, 
 // (the list could then not be closed and is rebuilt the exact way: still min(count, capacity) valid pairs).
 template <typename T>
 int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                            uint32_t n, void *scratch, const uint32_t *n_dev = nullptr) {
+                            uint32_t n, void *scratch, const uint32_t *n_dev = nullptr, uint32_t *walk_order = nullptr) {
     // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
     const bool split = (n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072);
     const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256);
@@ -1262,7 +1270,8 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
     const T *bd = (const T *)bounds;
     ChunkHdr *hdr = (ChunkHdr *)scratch;
     COL_HIP(hipMemsetAsync(hdr, 0, 64, s));
-    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn, NoGhost{}, n_dev);
+    k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn, NoGhost{}, n_dev,
+                                                   (dyn & 256) && !(g_traverse_variant & 2097152) ? walk_order : nullptr);
     COL_LAUNCH_OK();
     if (capacity) {
         k_pairs_compact<<<dim3(512), dim3(256), 0, s>>>(pairs, hdr, blocks);
@@ -1374,16 +1383,18 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 // the end.  *counter must be 0 on entry (the list starts here).  Record arrays below 4 GB and 64-byte aligned (what the
 // asm walks need); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
 static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
-                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev);
+                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev,
+                                uint32_t *walk_order = nullptr);
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
     return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, scratch, nullptr);
 }
 static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
-                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev) {
+                                const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev,
+                                uint32_t *walk_order) {
     const bool off32 = (coord_bytes == 4 || coord_bytes == 8) && (2ull * n - 1) * 8 * (unsigned)coord_bytes < (1ull << 32) &&
                        ((uintptr_t)bounds & 63) == 0;                                                // (see launch_traverse)
-    if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072)))
+    if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072 | 2097152)))
     {
         if (n < 2) return COL_OK;
         if (capacity > 0 && !pairs) return COL_EINVAL;
@@ -1393,8 +1404,8 @@ static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter
     }
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev);      // (round 4: the asm walk has a float64 form)
-    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev);
+    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order);      // (round 4: the asm walk has a float64 form)
+    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order);
 }
 
 // Diagnostics: same traversal, also accumulates stats[0..7] (8 x u64) = phase-2 steps, descents, leaf
@@ -1410,7 +1421,8 @@ int col_traverse_stats(void *stream, uint32_t *pairs, uint32_t *counter, uint32_
 size_t col_collide_scratch_bytes(uint32_t n, uint32_t padded, int coord_bytes) {
     return 256 /* scene range */ + col_reduce_scratch_bytes(coord_bytes == 8 ? COL_F64 : COL_F32, 4) +
            col_radix_scratch_bytes(padded, 4, 4) + col_lbvh_scratch_bytes(n, coord_bytes) +
-           (size_t)n * 4 * coord_bytes /* packed (x,y,z,r) rows */ + sizeof(ChunkHdr) + 256 /* chunked pair allocation */ + 1024;
+           (size_t)n * 4 * coord_bytes /* packed (x,y,z,r) rows */ + sizeof(ChunkHdr) + 256 /* chunked pair allocation */ + 1024 +
+           8 * ((size_t)n / 64 + 1) + 256 /* walk order: cost[] + perm[] */;
 }
 
 int col_collide(void *stream, const void *coords, const void *radii, uint32_t n, uint32_t padded, int coord_bytes,
@@ -1502,11 +1514,14 @@ int col_collide_plan_dev(void *stream, const void *coords, const void *radii, ui
     // the traversal's packet counters (dynamic packet order, k_traverse): cleared by the tree build's last kernel
     // (variant bit 15: from any size, so that the small parity cases of tests/ take this way too)
     uint32_t *sched = (!chunked && (n >= COL_DYNAMIC_PACKETS_FROM || (g_traverse_variant & 32768))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr)) : nullptr;
-    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev))) return rc;
-    if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev);
+    // the walk order (col_common.h): cost[] and perm[] behind the chunk header, wherever the dynamic packet order runs and the tree
+    // build ends with k_cross (more than one chunk)
+    uint32_t *walk_order = ((sched || chunked) && n > 256) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr) + 256) : nullptr;
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev, walk_order))) return rc;
+    if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev, walk_order);
     if (n < 2) return COL_OK;
-    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev);
-    return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev);
+    if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev, walk_order);
+    return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev, walk_order);
 }
 
 }  // extern "C"

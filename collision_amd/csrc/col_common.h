@@ -27,7 +27,8 @@ extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes,
                            uint32_t *zero8,       // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
-                           const uint32_t *n_dev);   // device-side count (see col_morton_tile), or NULL
+                           const uint32_t *n_dev,    // device-side count (see col_morton_tile), or NULL
+                           uint32_t *walk_order);    // the traversal's cost / order arrays (COL_WALK_ORDER below), or NULL
 extern "C" int col_radix_sort_msd_dev(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
                                       uint64_t n, void *scratch, uint32_t *oversize, const uint32_t *n_real_dev);   // radix.hip
 
@@ -137,6 +138,18 @@ __device__ __forceinline__ u32 block_link(u32 lo, u32 hi) { return COL_LINK_MARK
 // the skip links of the leaves then lead through the whole block (nested blocks are entered the same way)
 __device__ __forceinline__ u32 descend_link(u32 down, u32 leaf_start, bool marks) {
     return (marks && (down & COL_LINK_MARK)) ? leaf_start + ((down >> 4) & 0x7FFFFFFu) : down;
+}
+// ---- WALK ORDER (round 4): the traversal's dynamic packet order hands out an XCD's walks LONGEST FIRST, by what each packet's
+// walk took in the PREVIOUS call on the same scratch (any order is correct; a scene that changes little from call to call -- a
+// simulation, a benchmark loop -- gets the makespan of a longest-first list schedule instead of a tail of late long walks).
+// walk_order = cost[npk] then perm[npk] (u32 each, npk = packets of the BOUND n): k_traverse writes a packet's walk time into cost[],
+// the tree build's last launch (k_cross: eight extra workgroups, one per XCD) turns the previous costs into perm[] -- per XCD range,
+// eight classes by cost / mean, longer classes first -- and k_traverse maps walk unit u to packet perm[u].
+#define COL_TRAV_WAVES 16u      // packets per batch of the dynamic order = waves per k_traverse workgroup (bvh.hip TW)
+__device__ __forceinline__ void xcd_packet_range(u32 npackets, u32 x, u32 &p_lo, u32 &p_end) {
+    const u32 ng = (npackets + COL_TRAV_WAVES - 1) / COL_TRAV_WAVES;
+    p_lo = (u32)(((u64)ng * x) >> 3) * COL_TRAV_WAVES;
+    p_end = min((u32)(((u64)ng * (x + 1)) >> 3) * COL_TRAV_WAVES, npackets);
 }
 // ---- 30-bit Morton codes (collision.cl:14-31); shared by morton.hip and multi.hip ----
 __device__ __forceinline__ u32 expand_bits(u32 v) {   // collision.cl:14-20

@@ -640,8 +640,52 @@ __device__ __forceinline__ void cross_node(T *__restrict__ bounds, const u32 *__
 template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
                                                const T *__restrict__ partial, const u32 *__restrict__ cross, Tabs tabs, u32 n,
-                                               u32 nchunks, int lin, u32 *__restrict__ zero8, const u32 *__restrict__ n_dev) {
+                                               u32 nchunks, int lin, u32 *__restrict__ zero8, const u32 *__restrict__ n_dev,
+                                               u32 *__restrict__ walk_order, u32 cross_blocks, int force_order) {
+    const u32 n_bound = n;
     if (n_dev) { n = count_of(n, n_dev); nchunks = min(nchunks, (n + (u32)C - 1) / (u32)C); }
+    if (blockIdx.x >= cross_blocks) {
+        // WALK ORDER (col_common.h): workgroup x of these eight sorts XCD x's packets into eight classes by the cost the previous
+        // call's walk left for them (cost * 4 / mean, capped), longest class first; inside a class any order (an LDS cursor).
+        __shared__ unsigned long long s_sum, s_sq;
+        __shared__ u32 s_cnt[8], s_cur[8];
+        const u32 x = blockIdx.x - cross_blocks, npk_bound = (n_bound + 63u) / 64u;
+        const u32 *cost = walk_order;
+        u32 *perm = walk_order + npk_bound;
+        u32 p_lo, p_end;
+        xcd_packet_range((n + 63u) / 64u, x, p_lo, p_end);
+        if (threadIdx.x == 0) { s_sum = 0; s_sq = 0; }
+        if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long mine = 0, mine_sq = 0;
+        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) {
+            const unsigned long long c = min(cost[q], 1u << 24);        // (garbage of a first call must not overflow the squares)
+            mine += c;
+            mine_sq += c * c;
+        }
+        atomicAdd(&s_sum, mine);
+        atomicAdd(&s_sq, mine_sq);
+        __syncthreads();
+        const u32 cnt = p_end > p_lo ? p_end - p_lo : 0u;
+        const unsigned long long mean = cnt ? max(s_sum / cnt, 1ull) : 1ull;
+        // Only where the walks really differ: the order scatters a batch's 16 packets over the XCD's range (neighbouring packets
+        // walk nearly the same nodes), and on a uniform scene -- walk times within +-40 % of their mean, much of that the
+        // contention of the moment -- that costs what the order gains (2 M uniform + 2 %, 1 M - 1 %), while config 3's
+        // packets differ by 5 x (1 M - 6 %, 2 M - 9.5 %).  The order is used where the walks are LONG (mean >= 3000 ticks of
+        // s_memtime's 100 MHz = 30 us: config 3's take 237 us, config 2's 13) or differ a lot (squared coefficient of variation
+        // >= 0.25; measured per XCD: 0.11-0.13 on config 2, 0.22-0.27 on config 3).
+        if (!cnt || (!force_order && mean < 3000ull && (s_sq / cnt) * 100ull < 125ull * mean * mean)) {
+            for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) perm[q] = q;
+            return;
+        }
+        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) atomicAdd(&s_cnt[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 acc = 0; for (int k = 7; k >= 0; k--) { s_cur[k] = acc; acc += s_cnt[k]; } }
+        __syncthreads();
+        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256)
+            perm[p_lo + atomicAdd(&s_cur[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u)] = q;
+        return;
+    }
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (zero8 && t < 8) zero8[t] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
     const u32 chunk = t / CROSS_CAP, slot = t % CROSS_CAP;
@@ -686,7 +730,7 @@ Layout layout(uint32_t n, int coord_bytes) {
 
 template <typename T>
 int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
-        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev) {
+        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev, u32 *walk_order) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
@@ -697,9 +741,10 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     // mode bit 10 (1024) alone is not a diagnostics mode: it selects the round-3 production instance -- shuffle scans, branchy
     // delta() -- for A/Bs (tools/lbvh_scan_ab.py)
     // (bit 11 (2048), likewise: float64 keeps the shuffle scans -- the A/B of the float64 DPP scans)
-    if (g_dbg & ~(1024 | 2048))
+    // (bit 12 (4096): the traversal's walk order is used whatever the previous costs look like -- tests)
+    if (g_dbg & ~(1024 | 2048 | 4096))
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                    (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOn{g_dbg & ~(1024 | 2048)});
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOn{g_dbg & ~(1024 | 2048 | 4096)});
     else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))
         k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                                  (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
@@ -725,8 +770,9 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         COL_LAUNCH_OK();
         if (groups < 2) break;
     }
-    k_cross<T><<<dim3((unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin,
-                                                                                                     zero8, n_dev);
+    const unsigned cross_blocks = (unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256);
+    k_cross<T><<<dim3(cross_blocks + (walk_order ? 8u : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8, n_dev,
+                                                                                walk_order, cross_blocks, (g_dbg & 4096) ? 1 : 0);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -743,22 +789,22 @@ size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, co
 // `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
 int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                 const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8,
-                const uint32_t *n_dev) {
+                const uint32_t *n_dev, uint32_t *walk_order) {
     if (n == 0) return COL_OK;
     if (n >= 0x80000000u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
         return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
-                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev);
+                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev, walk_order);
     if (coord_bytes == 8)
         return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
-                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev);
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev, walk_order);
     return COL_EINVAL;
 }
 
 int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
              col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
-    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr, nullptr);
+    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -489,16 +489,20 @@ def test_dense_scenes_switch_to_chunked_allocation_on_their_own(hip_env, oracle)
     assert [p & 2 for p in plans] == [0, 0, 2, 2], plans          # call k's count is published by call k + 1, seen by call k + 2
 
 
+@pytest.mark.parametrize("order", [False, True])
 @pytest.mark.parametrize("scene", ["uniform_f32", "uniform_f64", "clustered", "ragged_last_packet", "tiny_capacity",
                                    "back_to_back"])
-def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene):
+def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene, order):
     """From 1.5 M spheres on (and always with chunked allocation) the traversal's workgroups draw their packets from
     per-XCD counters instead of a fixed stride (csrc/bvh.hip: dynamic packet order; the counters are cleared by the tree
     build's last kernel).  col_debug_traverse bit 15 makes every size take that way: same arrays, same pair set, also
-    when the same collider runs again (the counters must be cleared every time) and with a list that is too small."""
+    when the same collider runs again (the counters must be cleared every time) and with a list that is too small.
+    `order`: the walks are handed out by the cost the previous call's walks left in the collider's scratch (col_common.h: WALK
+    ORDER; garbage on a first call, real times on the later calls of "back_to_back") -- any order gives the same pairs."""
     from collision_amd._lib import cdll
     lib = cdll()
     lib.col_debug_traverse(32768)
+    lib.col_debug_lbvh(4096 if order else 0)         # round 4: + the longest-first walk order, whatever the previous costs
     try:
         if scene == "uniform_f32":
             coords, radii = uniform_scene(300000, 0.004, "float32")
@@ -528,6 +532,7 @@ def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene):
                 assert_same_pair_set(pairs, ref["pairs"])
     finally:
         lib.col_debug_traverse(0)
+        lib.col_debug_lbvh(0)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
