@@ -674,8 +674,10 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
         // packets differ by 5 x (1 M - 6 %, 2 M - 9.5 %).  The order is used where the walks are LONG (mean >= 3000 ticks of
         // s_memtime's 100 MHz = 30 us: config 3's take 237 us, config 2's 13) or differ a lot (squared coefficient of variation
         // >= 0.25; measured per XCD: 0.11-0.13 on config 2, 0.22-0.27 on config 3).
-        if (!cnt || (!force_order && mean < 3000ull && (s_sq / cnt) * 100ull < 125ull * mean * mean)) {
-            for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) perm[q] = q;
+        if (!cnt) return;
+        const bool heavy = force_order == 1 || mean >= 3000ull || (s_sq / cnt) * 100ull >= 125ull * mean * mean;
+        if (!heavy) {              // (moderate scenes keep the natural order; moving only their few longest walks to the front
+            for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) perm[q] = q;      //  -- a stable partition -- was measured too: the same)
             return;
         }
         for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) atomicAdd(&s_cnt[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u);
