@@ -437,9 +437,26 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
     // take packets from the batch one by one (LDS word: end << 32 | cursor; the wave that finds cursor == end installs
     // the next batch, later ones wait for it; end = ~0: the XCD's range is used up).
     __shared__ unsigned long long s_sched;
+    // (the workgroup's FIRST batch is the one its place on the XCD names -- no atomic: 64 workgroups asking one counter at the
+    // start of the launch are served one after the other -- and the counter hands out the batches behind those; mode bit 7
+    // draws the first one too: the A/B.  s_use_perm: did this call's k_cross order this XCD's packets (WALK ORDER below)?)
+    __shared__ u32 s_use_perm;
+    __shared__ u32 s_walk_t0[TW], s_ncost[TW];
+    __shared__ uint2 s_costbuf[TW][8];        // (packet, ticks) of a wave's last walks: stored eight at a time, see WALK ORDER below
     const bool dyn = !STATS && !GHOST && (mode & 256) != 0 && !plain;
     if (dyn) {
-        if (threadIdx.x == 0) s_sched = 0;
+        if (threadIdx.x == 0) {
+            unsigned long long word = 0;
+            if (!(mode & 128)) {
+                const u32 p_lo = g_lo * TW, p_end = min(g_hi * (u32)TW, npackets);
+                const u32 p_hi = (mode & 512) ? p_end + (p_end - min(p_lo, p_end)) : p_end;
+                const u32 nb = p_lo + slot * (u32)TW;
+                word = nb >= p_hi ? 0xFFFFFFFF00000000ull : (((unsigned long long)min(nb + (u32)TW, p_hi) << 32) | nb);
+            }
+            s_sched = word;
+            s_use_perm = walk_order ? walk_order[2u * ((n_bound + 63u) / 64u) + xcd] : 0u;
+        }
+        if (threadIdx.x < TW) s_ncost[threadIdx.x] = 0;
         __syncthreads();
     }
     for (;;) {
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                     u32 *sched_ctr = ((mode & 32) ? reinterpret_cast<ChunkHdr *>(stats)->pad : reinterpret_cast<u32 *>(stats)) + x;
                     u32 nb = 0;
                     if (lane == 0) nb = atomicAdd(sched_ctr, (u32)TW);
-                    nb = p_lo + (u32)__builtin_amdgcn_readfirstlane((int)nb);
+                    nb = p_lo + ((mode & 128) ? 0u : slots * (u32)TW) + (u32)__builtin_amdgcn_readfirstlane((int)nb);
                     // (one store for both outcomes: two `if (lane == 0)` blocks with a `break` between them end in
                     // "illegal VGPR to SGPR copy" in hipcc's backend)
                     const bool none = nb >= p_hi;
@@ -496,7 +513,13 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // WALK ORDER (col_common.h): walk unit u of the dynamic order is packet perm[u] -- the XCD's packets, longest walk of the
         // previous call first; the walk's time goes into cost[] for the next call
         const bool ordered = !STATS && !GHOST && dyn && walk_order != nullptr && !only1;
-        if (ordered) packet = (u32)__builtin_amdgcn_readfirstlane((int)walk_order[(n_bound + 63u) / 64u + packet]);
+        if (ordered && __builtin_amdgcn_readfirstlane((int)s_use_perm)) {
+            // (bit 31: one of the XCD's long walks -- the launch ends when the last of them does, so it runs at raised wave priority
+            // among the 7 other walks of its SIMD; mode bit 10 ignores the bit: the A/B)
+            const u32 e = (u32)__builtin_amdgcn_readfirstlane((int)walk_order[(n_bound + 63u) / 64u + packet]);
+            packet = e & 0x7FFFFFFFu;
+            if ((e >> 31) && !(mode & 1024)) __builtin_amdgcn_s_setprio(3);
+        }
         const u32 q0 = packet * 64, q = q0 + lane;
         u64 prof_t0 = 0, prof_t1 = 0, prof_t2 = 0;
         if constexpr (PROF) prof_t0 = wall_clock64();
@@ -634,7 +657,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
         if ((mode & 2) || only1) idx = END;
-        const u64 walk_t0 = ordered ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (ordered && lane == 0) s_walk_t0[w] = (u32)__builtin_amdgcn_s_memtime();      // (in LDS: two scalar registers held across the walk cost it 8-11 %)
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             const char *rows_b = reinterpret_cast<const char *>(rows);
             const u32 buf_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)sink.buf;      // this wave's staging area
@@ -954,7 +977,18 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
                 idx = (u32)__builtin_amdgcn_readfirstlane((int)next);
             }
         }
-        if (ordered && lane == 0) walk_order[packet] = (u32)min(__builtin_amdgcn_s_memtime() - walk_t0, 0xFFFFFFFFull);
+        if (ordered) {
+            // (the walk's time goes to cost[] through a wave-private LDS list, eight walks per store instruction and the rest when the
+            // wave leaves: a store per walk put its acknowledgement -- vmcnt counts stores too -- in front of the next packet's
+            // record loads: + 7 % at 2 M spheres, + 16 % at 16 M)
+            const u32 k = s_ncost[w];
+            if (lane == 0) {
+                s_costbuf[w][k] = make_uint2(packet, (u32)__builtin_amdgcn_s_memtime() - s_walk_t0[w]);
+                s_ncost[w] = k == 7u ? 0u : k + 1u;
+            }
+            if (k == 7u && lane < 8) { const uint2 e = s_costbuf[w][lane]; walk_order[e.x] = e.y; }
+            __builtin_amdgcn_s_setprio(0);
+        }
         if constexpr (PROF) {
             const u64 prof_t3 = wall_clock64();
             if (lane == 0 && packet < COL_PROF_PACKETS && !only1)
@@ -962,6 +996,10 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         }
     }
 
+    if (dyn && walk_order) {
+        const u32 k = s_ncost[w];
+        if (lane < k) { const uint2 e = s_costbuf[w][lane]; walk_order[e.x] = e.y; }
+    }
     if (!STATS && sink.chunk) {
         // chunked allocation: the leftovers go the same way; then the block records what it leaves unused of its last
         // chunk, and the LAST block to get here sums up: T = slots allocated - holes = the number of pairs
@@ -1139,6 +1177,8 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     }
     if (sched && !st && !(g_traverse_variant & (16384 | 1 | 2 | 4 | 128 | 1024))) {      // (the other walks are A/B material)
         mode |= 256;
+        if (g_traverse_variant & 4194304) mode |= 128;      // A/B: the first batch drawn from the counter too
+        if (g_traverse_variant & 8388608) mode |= 1024;     // A/B: long walks at the ordinary priority
         if ((n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072)) mode |= 512;      // split units
         if (off32 && (g_traverse_variant & 4096)) k_traverse<T, false, false, 1, false, true><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev, (g_traverse_variant & 2097152) ? nullptr : walk_order);
         else if (off32) k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)sched, mode, NoGhost{}, n_dev, (g_traverse_variant & 2097152) ? nullptr : walk_order);
@@ -1261,7 +1301,7 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
                             uint32_t n, void *scratch, const uint32_t *n_dev = nullptr, uint32_t *walk_order = nullptr) {
     // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
     const bool split = (n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072);
-    const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256);
+    const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256) | ((g_traverse_variant & 4194304) ? 128 : 0) | ((g_traverse_variant & 8388608) ? 1024 : 0);
     const u32 npackets = (n + 63) / 64;
     u32 blocks = (u32)col_ceil_div(npackets, TW);
     if (blocks > 512) blocks = 512;
@@ -1394,7 +1434,7 @@ static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter
                                 uint32_t *walk_order) {
     const bool off32 = (coord_bytes == 4 || coord_bytes == 8) && (2ull * n - 1) * 8 * (unsigned)coord_bytes < (1ull << 32) &&
                        ((uintptr_t)bounds & 63) == 0;                                                // (see launch_traverse)
-    if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072 | 2097152)))
+    if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608)))
     {
         if (n < 2) return COL_OK;
         if (capacity > 0 && !pairs) return COL_EINVAL;
@@ -1516,8 +1556,11 @@ int col_collide_plan_dev(void *stream, const void *coords, const void *radii, ui
     uint32_t *sched = (!chunked && (n >= COL_DYNAMIC_PACKETS_FROM || (g_traverse_variant & 32768))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr)) : nullptr;
     // the walk order (col_common.h): cost[] and perm[] behind the chunk header, wherever the dynamic packet order runs and the tree
     // build ends with k_cross (more than one chunk)
-    uint32_t *walk_order = ((sched || chunked) && n > 256) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr) + 256) : nullptr;
-    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev, walk_order))) return rc;
+    // WALK ORDER (col_common.h): a dense scene orders its walks longest first, a sparse one of up to COL_DEAL_MAX_N spheres deals its
+    // long walks over the first round; larger sparse scenes record and order nothing
+    const int order_mode = chunked || col_lbvh_order_forced() ? 1 : 0;
+    uint32_t *walk_order = n > 256 && (chunked || (sched && (n <= COL_DEAL_MAX_N || order_mode))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr) + 256) : nullptr;
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev, walk_order, order_mode))) return rc;
     if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev, walk_order);
     if (n < 2) return COL_OK;
     if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev, walk_order);

@@ -28,7 +28,9 @@ extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes,
                            uint32_t *zero8,       // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
                            const uint32_t *n_dev,    // device-side count (see col_morton_tile), or NULL
-                           uint32_t *walk_order);    // the traversal's cost / order arrays (COL_WALK_ORDER below), or NULL
+                           uint32_t *walk_order,     // the traversal's cost / order arrays (WALK ORDER below), or NULL
+                           int order_mode);          // 1: a dense scene -- longest walks first; 0: only deal the long walks of a small launch
+extern "C" int col_lbvh_order_forced(void);      // col_debug_lbvh bit 12: the tests' switch for order_mode 1 at every size
 extern "C" int col_radix_sort_msd_dev(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
                                       uint64_t n, void *scratch, uint32_t *oversize, const uint32_t *n_real_dev);   // radix.hip
 
@@ -142,10 +144,16 @@ __device__ __forceinline__ u32 descend_link(u32 down, u32 leaf_start, bool marks
 // ---- WALK ORDER (round 4): the traversal's dynamic packet order hands out an XCD's walks LONGEST FIRST, by what each packet's
 // walk took in the PREVIOUS call on the same scratch (any order is correct; a scene that changes little from call to call -- a
 // simulation, a benchmark loop -- gets the makespan of a longest-first list schedule instead of a tail of late long walks).
-// walk_order = cost[npk] then perm[npk] (u32 each, npk = packets of the BOUND n): k_traverse writes a packet's walk time into cost[],
-// the tree build's last launch (k_cross: eight extra workgroups, one per XCD) turns the previous costs into perm[] -- per XCD range,
-// eight classes by cost / mean, longer classes first -- and k_traverse maps walk unit u to packet perm[u].
+// walk_order = cost[npk] then perm[npk] (u32 each, npk = packets of the BOUND n) then eight words "perm in use on XCD x": k_traverse
+// writes a packet's walk time into cost[]; the tree build's last launch (k_cross: 8 x COL_ORDER_SLICES extra workgroups) turns the
+// previous costs into perm[] per XCD range, and k_traverse maps walk unit u to packet perm[u] & 0x7FFFFFFF (bit 31: a long walk,
+// run at raised wave priority).  Two modes (lbvh.hip): a DENSE scene (chunked pair allocation: its walks differ by 5 x) gets eight
+// classes by cost / mean, longest first; any other scene of up to COL_DEAL_MAX_N spheres (a launch of two or three rounds) only
+// has its few long walks dealt over the first round's batches, everything else in natural order.  Larger sparse scenes: nothing
+// (walk_order = NULL -- no times recorded, no order: both cost more there than they gain).
+#define COL_DEAL_MAX_N 1310720u     // 8 XCDs x 2560 packets x 64
 #define COL_TRAV_WAVES 16u      // packets per batch of the dynamic order = waves per k_traverse workgroup (bvh.hip TW)
+#define COL_TRAV_FIRST_BATCHES 64      // workgroups of the traversal's grid per XCD (512 / 8): the batches that start at once
 __device__ __forceinline__ void xcd_packet_range(u32 npackets, u32 x, u32 &p_lo, u32 &p_end) {
     const u32 ng = (npackets + COL_TRAV_WAVES - 1) / COL_TRAV_WAVES;
     p_lo = (u32)(((u64)ng * x) >> 3) * COL_TRAV_WAVES;

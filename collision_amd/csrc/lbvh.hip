@@ -603,6 +603,8 @@ struct Tabs { void *t[3]; };
 // `lin`: the table level whose sparse table was not built because it has at most LIN entries (one
 // launch less on inputs up to 2 M leaves); a range on that level is a short scan of its level-0 row.
 constexpr u32 LIN = 32;
+constexpr u32 COL_ORDER_SLICES = 8;     // workgroups per XCD that order its packets (k_cross)
+constexpr u32 COL_DEAL_UPTO = COL_DEAL_MAX_N / 512;      // packets per XCD up to which a sparse scene's long walks are dealt (k_cross)
 
 template <typename T>
 __device__ __forceinline__ void cross_node(T *__restrict__ bounds, const u32 *__restrict__ other_end, const T *__restrict__ partial,
@@ -641,51 +643,122 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
                                                const T *__restrict__ partial, const u32 *__restrict__ cross, Tabs tabs, u32 n,
                                                u32 nchunks, int lin, u32 *__restrict__ zero8, const u32 *__restrict__ n_dev,
-                                               u32 *__restrict__ walk_order, u32 cross_blocks, int force_order) {
+                                               u32 *__restrict__ walk_order, u32 cross_blocks, int order_mode) {
     const u32 n_bound = n;
     if (n_dev) { n = count_of(n, n_dev); nchunks = min(nchunks, (n + (u32)C - 1) / (u32)C); }
     if (blockIdx.x >= cross_blocks) {
-        // WALK ORDER (col_common.h): workgroup x of these eight sorts XCD x's packets into eight classes by the cost the previous
-        // call's walk left for them (cost * 4 / mean, capped), longest class first; inside a class any order (an LDS cursor).
-        __shared__ unsigned long long s_sum, s_sq;
+        // WALK ORDER (col_common.h): COL_ORDER_SLICES workgroups per XCD look at the costs the previous call's walks left for the
+        // XCD's packets and decide this call's order.  The statistics come from a sample of at most 1024 packets (every
+        // workgroup of the XCD takes the same one: 16 M spheres are 31 250 packets per XCD, and reading them all in one
+        // workgroup made this launch 105 us instead of 42).
+        __shared__ unsigned long long s_sum;
         __shared__ u32 s_cnt[8], s_cur[8];
-        const u32 x = blockIdx.x - cross_blocks, npk_bound = (n_bound + 63u) / 64u;
+        const u32 ob = blockIdx.x - cross_blocks, x = ob & 7u, g = ob >> 3, npk_bound = (n_bound + 63u) / 64u;
         const u32 *cost = walk_order;
         u32 *perm = walk_order + npk_bound;
         u32 p_lo, p_end;
         xcd_packet_range((n + 63u) / 64u, x, p_lo, p_end);
-        if (threadIdx.x == 0) { s_sum = 0; s_sq = 0; }
+        if (threadIdx.x == 0) s_sum = 0;
         if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        unsigned long long mine = 0, mine_sq = 0;
-        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) {
-            const unsigned long long c = min(cost[q], 1u << 24);        // (garbage of a first call must not overflow the squares)
-            mine += c;
-            mine_sq += c * c;
-        }
-        atomicAdd(&s_sum, mine);
-        atomicAdd(&s_sq, mine_sq);
-        __syncthreads();
         const u32 cnt = p_end > p_lo ? p_end - p_lo : 0u;
-        const unsigned long long mean = cnt ? max(s_sum / cnt, 1ull) : 1ull;
-        // Only where the walks really differ: the order scatters a batch's 16 packets over the XCD's range (neighbouring packets
-        // walk nearly the same nodes), and on a uniform scene -- walk times within +-40 % of their mean, much of that the
-        // contention of the moment -- that costs what the order gains (2 M uniform + 2 %, 1 M - 1 %), while config 3's
-        // packets differ by 5 x (1 M - 6 %, 2 M - 9.5 %).  The order is used where the walks are LONG (mean >= 3000 ticks of
-        // s_memtime's 100 MHz = 30 us: config 3's take 237 us, config 2's 13) or differ a lot (squared coefficient of variation
-        // >= 0.25; measured per XCD: 0.11-0.13 on config 2, 0.22-0.27 on config 3).
-        if (!cnt) return;
-        const bool heavy = force_order == 1 || mean >= 3000ull || (s_sq / cnt) * 100ull >= 125ull * mean * mean;
-        if (!heavy) {              // (moderate scenes keep the natural order; moving only their few longest walks to the front
-            for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) perm[q] = q;      //  -- a stable partition -- was measured too: the same)
+        const u32 stride = (cnt + 1023u) / 1024u, nsamp = stride ? (cnt + stride - 1u) / stride : 0u;
+        u32 sample[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                  // (the four loads of a thread go out together: each is a round trip to memory)
+            const u32 e = threadIdx.x + 256u * k;
+            sample[k] = e < nsamp ? min(cost[p_lo + e * stride], 1u << 24) : 0u;        // (a first call's garbage, capped)
+        }
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) mine += sample[k];
+        atomicAdd(&s_sum, mine);
+        __syncthreads();
+        const unsigned long long mean = nsamp ? max(s_sum / nsamp, 1ull) : 1ull;
+        u32 *use_perm = walk_order + 2u * npk_bound + x;       // read by k_traverse's workgroups of this XCD
+        if (!cnt) { if (threadIdx.x == 0 && g == 0) *use_perm = 0; return; }
+        // Which order: decided by the caller (col_common.h, WALK ORDER).  The walks' times themselves do not tell a dense scene from a
+        // large sparse one -- a walk of a 16 M-sphere uniform scene takes 25 us among its 8191 neighbours, and a longest-first order
+        // there (it scatters a batch's 16 neighbouring packets, which walk nearly the same nodes, over the XCD's range) cost the
+        // traversal 15 %.
+        if (order_mode != 1) {
+            if (g) return;
+            // Moderate scenes (config 2: walks of 7..38 us around a mean of 13, the same packets long in every call): the kernel
+            // ends when the last long walk does, so the long walks (>= 1.5 x the mean: one packet in twelve) must START in the
+            // first round -- but SPREAD over it: a CU's scalar unit is what its 32 walks share, and long walks in a row (a
+            // longest-first list puts sixteen into one workgroup) only slow each other down.  So they are dealt over the leading
+            // slots of the XCD's first COL_TRAV_FIRST_BATCHES batches (one per workgroup of the traversal's grid), the longest
+            // class (>= 2 x) first; every other packet keeps its natural order in the slots that remain.
+            // ... and only where the launch is a few rounds long (up to COL_DEAL_UPTO packets on the XCD: 1.3 M spheres): the order costs
+            // every packet a dependent load of its number (1 M: - 1.6 us net of that; 2 M: + 6 us, `gpurun_out/order_ab_6.txt`)
+            const u32 nb1 = min(cnt / (u32)COL_TRAV_WAVES, (u32)COL_TRAV_FIRST_BATCHES);
+            if (nb1 == 0 || cnt > COL_DEAL_UPTO) {
+                if (threadIdx.x == 0) *use_perm = 0;          // natural order: k_traverse does not read perm[]
+                return;
+            }
+            const u32 thr2 = (u32)min(2ull * mean, 0xFFFFFFFFull), thr1 = (u32)min(mean + mean / 2, 0xFFFFFFFFull);
+            if (threadIdx.x < 2) s_cur[threadIdx.x] = 0;
+            constexpr int PER = (int)(COL_DEAL_UPTO + 255u) / 256;       // a thread's packets: q = p_lo + 256 * k + threadIdx.x
+            u32 mycost[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const u32 q = p_lo + 256u * k + threadIdx.x;
+                mycost[k] = q < p_end ? min(cost[q], 1u << 24) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if (p_lo + 256u * k + threadIdx.x < p_end && mycost[k] >= thr1) atomicAdd(&s_cnt[mycost[k] >= thr2 ? 0 : 1], 1u);
+            __syncthreads();
+            const u32 l2 = s_cnt[0], l = l2 + s_cnt[1];
+            if (l == 0 || l > 8u * nb1) {
+                if (threadIdx.x == 0) *use_perm = 0;
+                return;
+            }
+            if (threadIdx.x == 0) *use_perm = 1;
+            const u32 per = l / nb1, rem = l % nb1;                      // batch j starts with per + (j < rem) long walks
+            const u32 cap_a = (u32)COL_TRAV_WAVES - per - 1u, cap_b = (u32)COL_TRAV_WAVES - per, in_a = rem * cap_a, in_ab = in_a + (nb1 - rem) * cap_b;
+            __shared__ u32 s_ws[4];
+            u32 shorts = 0;
+#pragma unroll
+            for (int kk = 0; kk < PER; kk++) {
+                const u32 q = p_lo + 256u * kk + threadIdx.x;
+                if (p_lo + 256u * kk >= p_end) break;
+                const u32 c = mycost[kk];
+                const bool is_short = q < p_end && c < thr1;
+                u32 tot;
+                const u32 r = shorts + block_excl_scan<256>(is_short ? 1u : 0u, s_ws, &tot);
+                shorts += tot;
+                if (q >= p_end) continue;
+                u32 pos;
+                if (is_short) {
+                    if (r < in_a) pos = (r / cap_a) * (u32)COL_TRAV_WAVES + per + 1u + r % cap_a;
+                    else if (r < in_ab) pos = (rem + (r - in_a) / cap_b) * (u32)COL_TRAV_WAVES + per + (r - in_a) % cap_b;
+                    else pos = nb1 * (u32)COL_TRAV_WAVES + (r - in_ab);
+                } else {
+                    const u32 k = c >= thr2 ? atomicAdd(&s_cur[0], 1u) : l2 + atomicAdd(&s_cur[1], 1u);
+                    pos = (k % nb1) * (u32)COL_TRAV_WAVES + k / nb1;
+                }
+                perm[p_lo + pos] = is_short ? q : q | 0x80000000u;        // (bit 31: walked at raised priority)
+            }
             return;
         }
-        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256) atomicAdd(&s_cnt[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u);
+        // Longest first: eight classes by cost * 4 / mean (capped), the longest class first, any order inside a class (an LDS
+        // cursor).  From 4096 packets the XCD's range is cut into COL_ORDER_SLICES slices, a workgroup each, and the slices' orders
+        // are interleaved (element k of slice g goes to place k * slices + g): longest first up to the slices' differences.
+        const u32 slices = cnt >= 4096u ? (u32)COL_ORDER_SLICES : 1u;
+        if (g >= slices) return;
+        if (threadIdx.x == 0 && g == 0) *use_perm = 1;
+        const u32 len = cnt / slices, longer = cnt % slices;                       // slice g: len + (g < longer) packets
+        const u32 s_lo = p_lo + g * len + min(g, longer), s_end = s_lo + len + (g < longer ? 1u : 0u);
+        for (u32 q = s_lo + threadIdx.x; q < s_end; q += 256) atomicAdd(&s_cnt[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u);
         __syncthreads();
         if (threadIdx.x == 0) { u32 acc = 0; for (int k = 7; k >= 0; k--) { s_cur[k] = acc; acc += s_cnt[k]; } }
         __syncthreads();
-        for (u32 q = p_lo + threadIdx.x; q < p_end; q += 256)
-            perm[p_lo + atomicAdd(&s_cur[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u)] = q;
+        for (u32 q = s_lo + threadIdx.x; q < s_end; q += 256) {
+            const u32 cls = (u32)min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean);
+            const u32 k = atomicAdd(&s_cur[cls], 1u);
+            perm[p_lo + (k < len ? k * slices + g : len * slices + g)] = cls >= 6u ? q | 0x80000000u : q;
+        }
         return;
     }
     const u32 t = blockIdx.x * 256 + threadIdx.x;
@@ -732,7 +805,7 @@ Layout layout(uint32_t n, int coord_bytes) {
 
 template <typename T>
 int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
-        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev, u32 *walk_order) {
+        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev, u32 *walk_order, int order_mode) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
@@ -773,8 +846,8 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         if (groups < 2) break;
     }
     const unsigned cross_blocks = (unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256);
-    k_cross<T><<<dim3(cross_blocks + (walk_order ? 8u : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8, n_dev,
-                                                                                walk_order, cross_blocks, (g_dbg & 4096) ? 1 : 0);
+    k_cross<T><<<dim3(cross_blocks + (walk_order ? 8u * COL_ORDER_SLICES : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8, n_dev,
+                                                                                walk_order, cross_blocks, order_mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -784,6 +857,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
 extern "C" {
 
 void col_debug_lbvh(int mode) { g_dbg = mode; }
+int col_lbvh_order_forced(void) { return (g_dbg & 4096) ? 1 : 0; }
 void col_debug_leaf_blocks(float k) { g_block_k = k; }
 
 size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, coord_bytes).total + 256; }
@@ -791,22 +865,22 @@ size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, co
 // `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
 int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                 const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8,
-                const uint32_t *n_dev, uint32_t *walk_order) {
+                const uint32_t *n_dev, uint32_t *walk_order, int order_mode) {
     if (n == 0) return COL_OK;
     if (n >= 0x80000000u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
         return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
-                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev, walk_order);
+                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode);
     if (coord_bytes == 8)
         return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
-                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev, walk_order);
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode);
     return COL_EINVAL;
 }
 
 int col_lbvh(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
              col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes) {
-    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr, nullptr, nullptr);
+    return col_lbvh_ex(stream, codes, ids, coords, radii, nullptr, nodes, bounds, scratch, n, coord_bytes, nullptr, nullptr, nullptr, 0);
 }
 
 }  // extern "C"

@@ -1,4 +1,5 @@
-"""Whole-path A/B of the longest-first walk order (col_debug_traverse bit 21 = 2097152 turns it off): python tools/order_ab.py [n ...]"""
+"""Whole-path A/B of col_debug_traverse variants, interleaved on one box: python tools/order_ab.py [n ...] [vVARIANT ...]
+(default: bit 21 = 2097152, no walk order, against production; bit 22 = 4194304: the first batch drawn from the counter too)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +8,9 @@ from collision_amd._lib import cdll
 from collision_amd.collision import Collider
 import bench
 ctx = hip.Context(); cq = hip.CommandQueue(ctx)
-for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000]:
+VARIANTS = [int(a[1:]) for a in sys.argv[1:] if a.startswith('v')] or [2097152, 0]
+NAMES = {2097152: 'natural order', 0: 'production', 4194304: 'first batch drawn', 6291456: 'natural, first batch drawn', 8388608: 'long walks at ordinary priority'}
+for n in [int(a) for a in sys.argv[1:] if not a.startswith('v')] or [1000000, 2000000]:
     scenes = [("uniform",) + tuple(bench.uniform_scene(n)) + (1 << 20,)]
     scenes[0][2][:] = bench.RADIUS * (1e6 / n) ** (1.0 / 3.0)
     if n <= 2000000:
@@ -17,7 +20,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000]:
         nb, pb = hip.Buffer(ctx, 4), hip.Buffer(ctx, cap * 8)
         col = Collider(ctx, n, 64, 256)
         ref = None
-        for variant in (2097152, 0, 2097152, 0, 2097152, 0):
+        for variant in VARIANTS * 3:
             cdll().col_debug_traverse(variant)
             def step():
                 col.get_collisions(cq, cb, rb, nb, pb, cap)
@@ -28,6 +31,6 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000]:
             if ref is None: ref = pairs
             same = pairs.shape == ref.shape and bool((pairs == ref).all())
             ms = bench.time_events(hip, cq, step, 30)
-            print("n %9d %-8s %s: %.4f ms, pairs %d, same set: %s" % (n, name, {2097152: "natural order", 0: "longest first"}[variant], ms, cnt, same), flush=True)
+            print("n %9d %-8s %s: %.4f ms, pairs %d, same set: %s" % (n, name, NAMES.get(variant, str(variant)), ms, cnt, same), flush=True)
         cdll().col_debug_traverse(0)
         del cb, rb, nb, pb, col
