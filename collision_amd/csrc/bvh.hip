@@ -657,6 +657,10 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
         if ((mode & 2) || only1) idx = END;
+        if (mode & (2048 | 4096)) {      // diagnostics (variant bits 24 / 25): the walk with the lower / upper half of the packet's queries only
+            const bool keep = (mode & 2048) ? lane < 32u : lane >= 32u;
+            if (!keep) { lx = ly = lz = (T)INFINITY; hx = hy = hz = -(T)INFINITY; }
+        }
         if (ordered && lane == 0) s_walk_t0[w] = (u32)__builtin_amdgcn_s_memtime();      // (in LDS: two scalar registers held across the walk cost it 8-11 %)
         if constexpr (sizeof(T) == 4 && WALK == 1 && !VEC) {
             const char *rows_b = reinterpret_cast<const char *>(rows);
@@ -1148,6 +1152,8 @@ int launch_traverse(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t c
     if (g_traverse_variant & 16) mode |= 8;       // plain packet order
     if (g_traverse_variant & 256) mode |= 1;      // timing ablation: skip phase 1 (pairs inside the packets)
     if (g_traverse_variant & 512) mode |= 2;      // timing ablation: skip phase 2 (the walk)
+    if (g_traverse_variant & 16777216) mode |= 2048;      // timing experiment: the walk for lanes 0..31 only
+    if (g_traverse_variant & 33554432) mode |= 4096;      // ... for lanes 32..63 only
     // (diagnostics buffers: one per device, allocated on first use and kept; variant bits 10 and 13 only)
     constexpr int MAX_DEV = 16;
     static u64 *spread_dev[MAX_DEV] = {nullptr};   // timing ablation: per-wave flush counters (variant bit 10)

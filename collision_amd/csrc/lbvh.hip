@@ -171,6 +171,9 @@ template <typename I, bool FAST> __device__ __forceinline__ int delta(const Code
         const bool inb = (u32)j < c.n;                     // 0 <= j < n
         const u32 o = (u32)(j - c.w0);
         const bool inwin = o < (u32)WIN;
+#ifdef COL_EXP_NO_FAR      // timing experiment: no probe leaves the code window (wrong trees)
+        if (!inwin) return -1;
+#endif
         u32 cj;
         if (__builtin_amdgcn_ballot_w64(inb && !inwin) == 0) cj = c.win[inwin ? o : 0u];
         else cj = inb ? (inwin ? c.win[o] : c.g[j]) : 0u;
@@ -217,8 +220,11 @@ template <typename T> struct ChunkLds {
     u32 ready[C + 1];                   // [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
     u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
-    int adj[C];                         // delta(p, p + 1) of the chunk's own positions (FAST_DELTA: see k_chunk)
+    int adj[C + 1];                     // adj[1 + t] = delta(p, p + 1) of the chunk's position t, adj[0] = delta(c0 - 1, c0) (FAST_DELTA: see k_chunk)
+    u32 meet[C];                        // CLIMB: the two children of the node that splits behind position t meet here (far end + 1 of the first)
+    u32 oe[C], split[C];                // CLIMB: other end and split of node c0 + t (chunk-local positions), NO_RANGE = not an in-chunk node
 };
+constexpr u32 NO_RANGE = 0xFFFFFFFFu;
 // The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
 // a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
 // goes through all its nodes instead.
@@ -360,7 +366,7 @@ template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
 __device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
 __device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
 
-template <typename T, bool DIAG, typename I, bool DPP_SCAN = false, bool FAST_DELTA = false>
+template <typename T, bool DIAG, typename I, bool DPP_SCAN = false, bool FAST_DELTA = false, bool CLIMB = false>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
                                              const T *__restrict__ packed,
@@ -418,8 +424,10 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         const u32 cme = wcode[HALO / C];
         if (has_prev) d_prev = (int)min(ffbh_raw(cme ^ cprev), 32u + ffbh_raw(p ^ (p - 1u)));
         if (has_next) d_next = (int)min(ffbh_raw(cme ^ cnext), 32u + ffbh_raw(p ^ (p + 1u)));
-        lds.adj[tid] = d_next;
+        lds.adj[1 + tid] = d_next;
+        if (tid == 0) lds.adj[0] = d_prev;
     }
+    if constexpr (CLIMB) { lds.meet[tid] = 0; lds.oe[tid] = NO_RANGE; }
 #pragma unroll
     for (int k = 0; k < WIN / C; k++) s_codes[tid + k * C] = wcode[k];
     lds.ready[tid] = 0;
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
             if constexpr (FAST_DELTA && sizeof(I) == 4) {
                 const u32 k = p + 1;
                 if (k + 1 >= n) skip_leaf = (n - 1) + k;
-                else if (tid + 1 < C) skip_leaf = lds.adj[tid + 1] > d_next ? k : (n - 1) + k;
+                else if (tid + 1 < C) skip_leaf = lds.adj[tid + 2] > d_next ? k : (n - 1) + k;
                 else skip_leaf = right_child_at(codes, k);            // (the chunk's last leaf: adj[k] belongs to the next chunk)
             } else skip_leaf = right_child_at(codes, p + 1);
         }
@@ -490,54 +498,225 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if (tid == 0)          // chunk total -> level 0 of the first group table
         box_store(tab1, ((uint64_t)(chunk / C) * LV + 0) * C + (chunk % C), suf);
     if (p == n - 1 && n > (u32)C) box_store(partial, p, pre);      // prefix of the last leaf
-    if (p >= leaf_start || (dbg & 4)) return;                      // no barrier below this line
-
-    // internal node p: collision.cl:81-121 (Karras 2012)
-    const u32 i = p, ci = codes.win[HALO + tid];       // (= codes.at(i): the chunk's own codes are always in the window)
-    int dir, delta_min;
-    if constexpr (FAST_DELTA && sizeof(I) == 4) {
-        dir = d_next > d_prev ? 1 : -1;
-        delta_min = min(d_next, d_prev);                          // = delta(i, i - dir)
-    } else {
-        dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
-        delta_min = delta(codes, i, ci, (I)i - dir);
+    // CLIMB (round 4): the in-chunk nodes bottom-up instead of Karras' searches.  For sorted keys delta(i, j) is the minimum of the
+    // adjacent deltas between i and j (equal codes included: their deltas 32 + clz(i ^ j) are the common prefix of the keys
+    // (code, position)), so the tree is the Cartesian tree of adj[]: a finished range [l, r] is the LEFT child of its parent --
+    // Karras' node r -- if delta(r, r + 1) > delta(l - 1, l), else the right child -- node l --, and the two children of the node
+    // that splits behind position g meet at meet[g]: the first leaves its far end there and stops, the second takes over the
+    // union and goes on (Apetrei 2014, inside one chunk and in LDS).  One round costs what ONE of the search's probes did, a
+    // thread climbs as far as it arrives second, and the boxes are merged on the way: no search (22 probes per wave), no waiting
+    // for children.  A range whose sibling lies outside the chunk stops; its parent crosses the boundary and is found by the
+    // search below, like every node that the climb has not named (oe[] == NO_RANGE).
+    if constexpr (CLIMB) {
+        if (valid) {
+            int l = tid, r = tid, my_split = 0;
+            bool is_leaf = true;
+            Box<T> box = leaf;
+            for (;;) {
+                const int dl = lds.adj[l], dr = lds.adj[r + 1];
+                const bool right = dr > dl;
+                if (!is_leaf) {
+                    const int node = right ? r : l;
+                    soa_put(lds.node, node, box);
+                    lds.oe[node] = (u32)(right ? l : r);
+                    lds.split[node] = (u32)my_split;
+                }
+                const int g = right ? r : l - 1;
+                if ((dl & dr) < 0 || g < 0 || g >= C - 1) break;       // the root; or the sibling lies outside the chunk
+                // (LDS instructions of one wave are carried out in order: the box is in lds.node before the exchange, and the reads
+                // below come after it -- the compiler only has to keep that order)
+                asm volatile("" ::: "memory");
+                const u32 old = __hip_atomic_exchange(&lds.meet[g], (u32)(right ? l : r) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                if (old == 0) break;                                    // first: the sibling will take it from here
+                const int far = (int)old - 1;
+                Box<T> sib;
+                if (right) { sib = far == g + 1 ? soa_get(lds.leaf, g + 1) : soa_get(lds.node, g + 1); r = far; }
+                else { sib = far == g ? soa_get(lds.leaf, g) : soa_get(lds.node, g); l = far; }
+                box_merge(box, sib);
+                my_split = g;
+                is_leaf = false;
+            }
+        }
+        __syncthreads();
     }
-    I len_max = 2;
-    while (delta(codes, i, ci, (I)i + dir * len_max) > delta_min) len_max *= 2;
-    I len = 0;
-    for (I t = len_max / 2; t > 0; t /= 2)
-        if (delta(codes, i, ci, (I)i + dir * (len + t)) > delta_min) len += t;
-    const u32 j = (u32)((I)i + dir * len);
-    const int delta_node = delta(codes, i, ci, (I)j);
-    I s = 0, t = len;
-    do {
-        t = (t + 1) / 2;
-        if (delta(codes, i, ci, (I)i + dir * (s + t)) > delta_node) s += t;
-    } while (t > 1);
-    const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
-    const u32 lo = min(i, j), hi = max(i, j);
-    const bool a_leaf = lo == gamma, b_leaf = hi == gamma + 1;
-    const u32 child_a = a_leaf ? leaf_start + gamma : gamma;
-    const u32 child_b = b_leaf ? leaf_start + gamma + 1 : gamma + 1;
-    InnerTail tail = {hi, child_a, child_b};
-    *reinterpret_cast<InnerTail *>(&nodes[i].right_edge) = tail;
-    if (!(dbg & 2)) { nodes[child_a].parent = i; nodes[child_b].parent = i; }
-    other_end[i] = j;
-
-    u32 skip = END;
-    if (hi + 1 < n) {
+    // Karras' search (collision.cl:81-121) for node c0 + t: its other end and its split
+    auto search = [&](u32 t, u32 &j, u32 &gamma) {
+        const u32 i = c0 + t, ci = codes.win[HALO + t];       // (= codes.at(i): the chunk's own codes are always in the window)
+        int dir, delta_min;
         if constexpr (FAST_DELTA && sizeof(I) == 4) {
-            const u32 k = hi + 1;
-            if (k + 1 >= n) skip = (n - 1) + k;
-            else if (hi >= c0 && k < c0 + (u32)C) skip = lds.adj[k - c0] > lds.adj[hi - c0] ? k : (n - 1) + k;
-            else skip = right_child_at(codes, k);
-        } else skip = right_child_at(codes, hi + 1);
+            const int dn = lds.adj[t + 1], dp = lds.adj[t];   // delta(i, i + 1), delta(i - 1, i)
+            dir = dn > dp ? 1 : -1;
+            delta_min = min(dn, dp);                           // = delta(i, i - dir)
+        } else {
+            dir = delta(codes, i, ci, (I)i + 1) > delta(codes, i, ci, (I)i - 1) ? 1 : -1;
+            delta_min = delta(codes, i, ci, (I)i - dir);
+        }
+        I len_max = 2;
+        while (delta(codes, i, ci, (I)i + dir * len_max) > delta_min) len_max *= 2;
+        I len = 0;
+        for (I t2 = len_max / 2; t2 > 0; t2 /= 2)
+            if (delta(codes, i, ci, (I)i + dir * (len + t2)) > delta_min) len += t2;
+        j = (u32)((I)i + dir * len);
+        const int delta_node = delta(codes, i, ci, (I)j);
+        I s = 0, t2 = len;
+        do {
+            t2 = (t2 + 1) / 2;
+            if (delta(codes, i, ci, (I)i + dir * (s + t2)) > delta_node) s += t2;
+        } while (t2 > 1);
+        gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
+    };
+    // node c0 + t with its other end j and its split: the node record's tail, the children's parent words, the links; returns
+    // the skip link and the left child (collision.cl:104-120)
+    auto node_out = [&](u32 t, u32 j, u32 gamma, u32 &skip, u32 &child_a) {
+        const u32 i = c0 + t;
+        const u32 lo = min(i, j), hi = max(i, j);
+        const bool a_leaf = lo == gamma, b_leaf = hi == gamma + 1;
+        child_a = a_leaf ? leaf_start + gamma : gamma;
+        const u32 child_b = b_leaf ? leaf_start + gamma + 1 : gamma + 1;
+        InnerTail tail = {hi, child_a, child_b};
+        *reinterpret_cast<InnerTail *>(&nodes[i].right_edge) = tail;
+        if (!(dbg & 2)) { nodes[child_a].parent = i; nodes[child_b].parent = i; }
+        other_end[i] = j;
+        skip = END;
+        if (hi + 1 < n) {
+            if constexpr (FAST_DELTA && sizeof(I) == 4) {
+                const u32 k = hi + 1;
+                if (k + 1 >= n) skip = (n - 1) + k;
+                else if (hi >= c0 && k < c0 + (u32)C) skip = lds.adj[k - c0 + 1] > lds.adj[hi - c0 + 1] ? k : (n - 1) + k;
+                else {
+                    // (outside the chunk: the three codes in ONE round trip -- right_child_at's code read and two probes are three)
+                    const u32 ck = gcodes[k], cm = gcodes[k - 1u], cp = gcodes[k + 1u];
+                    const u32 d_fwd = min(ffbh_raw(ck ^ cp), 32u + ffbh_raw(k ^ (k + 1u))), d_bwd = min(ffbh_raw(ck ^ cm), 32u + ffbh_raw(k ^ (k - 1u)));
+                    skip = d_fwd > d_bwd ? k : (n - 1) + k;
+                }
+            } else skip = right_child_at(codes, hi + 1);
+        }
+    };
+    // a node whose range lies in this chunk: its record with the box, marked as a leaf block if it is small and dense
+    auto record_out = [&](u32 i, u32 j, u32 skip, u32 child_a, const Box<T> &box) {
+        // leaf block (col_common.h): a small DENSE node -- on every axis at most block_k times as wide as its first
+        // leaf -- is marked for the packet walk.  Sparse scenes (BASELINE config 2: leaf boxes a fifth of the
+        // spacing) get no marks and walk as before; where spheres overlap in heaps (config 3) nearly every node
+        // of <= 16 leaves qualifies.
+        const u32 lo = min(i, j), hi = max(i, j);
+        u32 down = child_a;
+        if (hi - lo < COL_LEAF_BLOCK && n <= COL_LEAF_BLOCK_MAX_N && block_k > (T)0) {
+            const Box<T> first = soa_get(lds.leaf, (int)(lo - c0));
+            bool dense = true;
+#pragma unroll
+            for (int k = 0; k < 3; k++) dense = dense && (box.hi[k] - box.lo[k]) <= block_k * (first.hi[k] - first.lo[k]);
+            if (dense) down = block_link(lo, hi);
+        }
+        record_store(bounds, (uint64_t)i, box, skip, down);
+    };
+    // a node that crosses the chunk's boundary leaves this chunk's half of its range -- the suffix from i (forward) or the prefix up
+    // to i (backward) -- and its number for k_cross
+    auto crossing_out = [&](u32 i, int dir) {
+        box_store(partial, i, dir > 0 ? suf : pre);
+        const u32 slot = atomicAdd(&lds.ncross, 1u);
+        cross[(uint64_t)chunk * CROSS_CAP + (slot < CROSS_CAP - 1 ? slot : CROSS_CAP - 1)] = slot < CROSS_CAP - 1 ? i : CROSS_DENSE;
+    };
+    if constexpr (CLIMB) {
+        // A node the climb has named: everything is known.  The others -- three in a hundred: their ranges cross the chunk's boundary --
+        // leave their half box themselves (the direction is in adj[]); what they still need is Karras' search, and what that costs
+        // is the ROUND TRIPS of the probes that leave the code window: a workgroup held its place on the CU while one lane asked
+        // global memory 10..30 times in a row (with those probes answered "no" the launch was 12 us shorter at 1 M spheres).  So
+        // a wave shares its lanes among its unnamed nodes -- 64, 32, 16 or 8 lanes per node -- and every step of the three searches
+        // (each looks for the end of a run of "yes": delta(i, i + dir * x) > threshold is monotone in x) asks that many places at
+        // once: the powers of two, then equal parts of what is left.  A fifth of the round trips, ~35 instructions per step for
+        // the whole wave, no barrier below the climb's.
+        // (Measured on the way: the searches compacted into the lanes of wave 0 behind two barriers: - 1 %; the same without
+        // barriers, after wave 0's own output: + 15 %; 7 places per step in every lane of wave 0: + 9 % -- 300 instructions per step.)
+        const bool inner = p < leaf_start;
+        const bool named = inner && lds.oe[tid] != NO_RANGE;
+        u32 skip, child_a;
+        if (named) {
+            const u32 j = c0 + lds.oe[tid];
+            node_out((u32)tid, j, c0 + lds.split[tid], skip, child_a);
+            record_out(p, j, skip, child_a, soa_get(lds.node, tid));
+        } else if (inner) crossing_out(p, d_next > d_prev ? 1 : -1);
+        const u64 todo = __builtin_amdgcn_ballot_w64(inner && !named);
+        if (todo == 0) return;
+        const u32 cnt = (u32)__builtin_popcountll(todo);
+        const u32 lpn_log = cnt <= 1 ? 6u : cnt <= 2 ? 5u : cnt <= 4 ? 4u : 3u, lpn = 1u << lpn_log, groups = 64u >> lpn_log;
+        const u32 g = (u32)lane >> lpn_log, sub = (u32)lane & (lpn - 1u);
+        auto group_count = [&](bool yes) -> I {             // how many lanes of my group say yes
+            u64 m = __builtin_amdgcn_ballot_w64(yes) >> (g << lpn_log);
+            if (lpn < 64u) m &= (1ull << lpn) - 1ull;
+            return (I)__builtin_popcountll(m);
+        };
+        for (u32 base = 0; base < cnt; base += groups) {
+            const bool on = base + g < cnt;                  // my group has a node this round
+            u64 m = todo;
+            for (u32 b = 0; b < base + g && on; b++) m &= m - 1ull;
+            const u32 t = on ? (u32)w * COL_WAVE + (u32)__builtin_ctzll(m) : (u32)tid;
+            const u32 i = c0 + t, ci = codes.win[HALO + t];
+            const int dn = lds.adj[t + 1], dp = lds.adj[t];   // delta(i, i + 1), delta(i - 1, i)
+            const int dir = dn > dp ? 1 : -1, delta_min = min(dn, dp);
+            // is place x (0 = none) in the run?  one load per lane; LDS if every lane's place is in the window
+            auto yes_at = [&](I x, int thr) -> bool {
+                const I jk = (I)i + dir * x;
+                const bool inb = on && x > 0 && (u32)jk < n;
+                const u32 o = (u32)(jk - codes.w0);
+                const bool inwin = o < (u32)WIN;
+                u32 cj;
+                if (__builtin_amdgcn_ballot_w64(inb && !inwin) == 0) cj = codes.win[inwin ? o : 0u];
+                else cj = inb ? (inwin ? codes.win[o] : gcodes[jk]) : 0u;
+                const u32 d = min(ffbh_raw(ci ^ cj), 32u + ffbh_raw(i ^ (u32)jk));
+                return inb && (int)d > thr;
+            };
+            // the first power of two that is not in the range any more
+            I hi = 2;
+            {
+                bool more = on;
+                int e0 = 1;
+                while (__builtin_amdgcn_ballot_w64(more)) {
+                    const int e = e0 + (int)sub;
+                    const I x = (more && e < 31 && (1u << e) <= n) ? (I)(1u << e) : (I)0;
+                    const I yes = group_count(yes_at(x, delta_min));
+                    if (more) {
+                        hi = (I)(1u << (e0 + yes));
+                        more = yes == (I)lpn && e0 + (int)lpn < 31;
+                        e0 += (int)lpn;
+                    }
+                }
+            }
+            // the end of a run of yes between lo (in) and hi (out)
+            auto run_end = [&](I lo, I hi, int thr) -> I {
+                while (__builtin_amdgcn_ballot_w64(on && hi - lo > 1)) {
+                    const bool act = on && hi - lo > 1;
+                    const I step = (hi - lo + (I)lpn) / ((I)lpn + 1);
+                    const I x = lo + ((I)sub + 1) * step;
+                    const I yes = group_count(yes_at(act && x < hi ? x : (I)0, thr));
+                    if (act) { lo += yes * step; hi = min(hi, lo + step); }
+                }
+                return lo;
+            };
+            const I len = run_end(hi / 2, hi, delta_min);
+            const u32 j = (u32)((I)i + dir * len);
+            const int delta_node = delta(codes, i, ci, (I)j);
+            const I s = run_end((I)0, len, delta_node);
+            const u32 gamma = dir > 0 ? (u32)(i + s) : (u32)(i - s - 1);
+            if (on && sub == 0) {
+                node_out(t, j, gamma, skip, child_a);
+                links_store(bounds, (uint64_t)i, skip, child_a);
+            }
+        }
+        return;
     }
+    if (p >= leaf_start || (dbg & 4)) return;                      // no barrier below this line
+    u32 j = 0, gamma = 0, skip, child_a;
+    search((u32)tid, j, gamma);
+    const u32 i = p;
+    const u32 lo = min(i, j), hi = max(i, j);
+    node_out((u32)tid, j, gamma, skip, child_a);
     if (dbg & 8) return;
     if (lo >= c0 && hi < c0 + C) {
         // Both children live in this chunk.  Wait (in LDS, workgroup scope) until their boxes are
         // final, merge, publish.  The tree is at most 64 levels deep, so this ends after <= 64
         // rounds; finished lanes idle at the loop exit while the others retry.
+        const bool a_leaf = lo == gamma, b_leaf = hi == gamma + 1;
         const int la = (int)(gamma - c0), lb = la + 1;
         Box<T> box;
         const int fa = a_leaf ? C : la, fb = b_leaf ? C : lb;      // both flags are read every round, unconditionally
@@ -554,25 +733,10 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                 done = true;
             }
         }
-        // leaf block (col_common.h): a small DENSE node -- on every axis at most block_k times as wide as its first
-        // leaf -- is marked for the packet walk.  Sparse scenes (BASELINE config 2: leaf boxes a fifth of the
-        // spacing) get no marks and walk as before; where spheres overlap in heaps (config 3) nearly every node
-        // of <= 16 leaves qualifies.
-        u32 down = child_a;
-        if (hi - lo < COL_LEAF_BLOCK && n <= COL_LEAF_BLOCK_MAX_N && block_k > (T)0) {
-            const Box<T> first = soa_get(lds.leaf, (int)(lo - c0));
-            bool dense = true;
-#pragma unroll
-            for (int k = 0; k < 3; k++) dense = dense && (box.hi[k] - box.lo[k]) <= block_k * (first.hi[k] - first.lo[k]);
-            if (dense) down = block_link(lo, hi);
-        }
-        record_store(bounds, (uint64_t)i, box, skip, down);
+        record_out(i, j, skip, child_a, box);
     } else {
         links_store(bounds, (uint64_t)i, skip, child_a);
-        // this chunk's half of the range: suffix from i (forward) or prefix up to i (backward)
-        box_store(partial, i, dir > 0 ? suf : pre);
-        const u32 slot = atomicAdd(&lds.ncross, 1u);
-        cross[(uint64_t)chunk * CROSS_CAP + (slot < CROSS_CAP - 1 ? slot : CROSS_CAP - 1)] = slot < CROSS_CAP - 1 ? i : CROSS_DENSE;
+        crossing_out(i, j > i ? 1 : -1);
     }
 }
 
@@ -817,11 +981,14 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     // delta() -- for A/Bs (tools/lbvh_scan_ab.py)
     // (bit 11 (2048), likewise: float64 keeps the shuffle scans -- the A/B of the float64 DPP scans)
     // (bit 12 (4096): the traversal's walk order is used whatever the previous costs look like -- tests)
-    if (g_dbg & ~(1024 | 2048 | 4096))
+    if (g_dbg & ~(1024 | 2048 | 4096 | 8192 | 16384))          // (bit 14: 24 KB of unused LDS per workgroup -- half the resident workgroups: a timing experiment)
         k_chunk<T, true, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                    (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOn{g_dbg & ~(1024 | 2048 | 4096)});
-    else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))
+                                                                    (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOn{g_dbg & ~(1024 | 2048 | 4096 | 8192 | 16384)});
+    else if (n < (1u << 30) && (g_dbg & 8192))         // (bit 13: Karras' searches for every node -- the A/B of the climb)
         k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
+                                                                                 (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
+    else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))       // production
+        k_chunk<T, false, int32_t, true, true, true><<<dim3(nchunks), dim3(C), (g_dbg & 16384) ? 24576 : 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                                  (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else if (n < (1u << 30) && !(g_dbg & 1024))
         k_chunk<T, false, int32_t, false, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,

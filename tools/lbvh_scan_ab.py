@@ -1,4 +1,5 @@
-"""A/B: k_chunk's prefix / suffix unions on the DPP network (production, f32) against the ds_bpermute shuffles
+"""COLLISION_LBVH_AB=<mode> (default 1024) names the col_debug_lbvh mode compared with production (8192: Karras' searches
+for every node instead of the climb).  Originally: k_chunk's prefix / suffix unions on the DPP network (production, f32) against the ds_bpermute shuffles
 (col_debug_lbvh(1024)): col_lbvh alone and the whole path, uniform scene, interleaved rounds in one process;
 the node boxes of the two variants are compared byte for byte."""
 import os, sys
@@ -9,6 +10,7 @@ from collision_amd._lib import call, cdll
 from collision_amd.collision import Collider
 import bench
 ctx = hip.Context(); cq = hip.CommandQueue(ctx)
+ALT = int(os.environ.get('COLLISION_LBVH_AB', '1024'))
 for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000, 16000000]:
     coords, radii = bench.uniform_scene(n)
     radii[:] = bench.RADIUS * (1e6 / n) ** (1.0 / 3.0)
@@ -26,7 +28,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000, 16000000]:
     res, boxes = {}, {}
     reps = 20 if n <= 4000000 else 6
     for rnd in range(3):
-        for mode in (1024, 0):
+        for mode in (ALT, 0):
             cdll().col_debug_lbvh(mode)
             for f, key in ((lbvh, "lbvh"), (path, "path")):
                 for _ in range(3):
@@ -37,7 +39,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1000000, 2000000, 16000000]:
                 lbvh(); cq.finish()
                 boxes[mode] = hip.read_buffer(cq, col._bounds_buf, np.uint32, (2 * n - 1) * 8).copy()
     cdll().col_debug_lbvh(0)
-    same = bool((boxes[0] == boxes[1024]).all())
+    same = bool((boxes[0] == boxes[ALT]).all())
     for key in ("lbvh", "path"):
-        print("n = %9d %s: shuffles %s | DPP %s ms   same boxes: %s" % (
-            n, key, " ".join("%.4f" % v for v in res[(1024, key)]), " ".join("%.4f" % v for v in res[(0, key)]), same), flush=True)
+        print(("n = %9d %s: mode " + str(ALT) + " %s | production %s ms   same boxes: %s") % (
+            n, key, " ".join("%.4f" % v for v in res[(ALT, key)]), " ".join("%.4f" % v for v in res[(0, key)]), same), flush=True)

@@ -1,7 +1,7 @@
 """Runs only the single-GPU path a few times, for rocprofv3 passes.
     python tools/path_only.py [steps] [n_spheres] [plan: auto|lsd|msd] [scene: uniform|config3] [leaf-block k] [traverse variant]
 (leaf-block k: col_debug_leaf_blocks, 0 = no marks; traverse variant: col_debug_traverse, 128 = the walk without block code;
-COLLISION_PATH_DTYPE=float64 in the environment: float64 coordinates and radii)"""
+COLLISION_PATH_DTYPE=float64 in the environment: float64 coordinates and radii; COLLISION_LBVH_MODE: col_debug_lbvh)"""
 import os
 import sys
 
@@ -34,6 +34,9 @@ if len(sys.argv) > 5:
     lib.col_debug_leaf_blocks(ctypes.c_float(float(sys.argv[5])))
     if len(sys.argv) > 6:
         lib.col_debug_traverse(int(sys.argv[6]))
+if os.environ.get("COLLISION_LBVH_MODE"):      # col_debug_lbvh (8192: Karras' searches instead of the climb)
+    from collision_amd._lib import cdll as _cdll
+    _cdll().col_debug_lbvh(int(os.environ["COLLISION_LBVH_MODE"]))
 col = Collider(ctx, n, bench.NGROUPS, bench.GROUP_SIZE, coord_dtype=dtype)
 col.sort_plan = plan
 for _ in range(steps):
