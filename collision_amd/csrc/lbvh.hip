@@ -217,11 +217,13 @@ template <typename T> __device__ __forceinline__ void links_store(T *bounds, uin
 template <typename T> struct ChunkLds {
     T leaf[6][C];
     T node[6][C];
-    u32 ready[C + 1];                   // [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
+    union {                             // (one or the other: 20 KB per workgroup are 8 workgroups per CU, 20.7 KB were 7)
+        u32 ready[C + 1];               // the searching instances; [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
+        u32 meet[C];                    // CLIMB: the two children of the node that splits behind position t meet here (far end + 1 of the first)
+    };
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
     u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
     int adj[C + 1];                     // adj[1 + t] = delta(p, p + 1) of the chunk's position t, adj[0] = delta(c0 - 1, c0) (FAST_DELTA: see k_chunk)
-    u32 meet[C];                        // CLIMB: the two children of the node that splits behind position t meet here (far end + 1 of the first)
     u32 oe[C], split[C];                // CLIMB: other end and split of node c0 + t (chunk-local positions), NO_RANGE = not an in-chunk node
 };
 constexpr u32 NO_RANGE = 0xFFFFFFFFu;
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     if constexpr (CLIMB) { lds.meet[tid] = 0; lds.oe[tid] = NO_RANGE; }
 #pragma unroll
     for (int k = 0; k < WIN / C; k++) s_codes[tid + k * C] = wcode[k];
-    lds.ready[tid] = 0;
+    if constexpr (!CLIMB) lds.ready[tid] = 0;
     if (tid < (int)CROSS_CAP) cross[(uint64_t)chunk * CROSS_CAP + tid] = END;       // (complete before the barrier below: the fence of __syncthreads)
-    if (tid == 0) { lds.ncross = 0; lds.ready[C] = 1u; }
+    if (tid == 0) { lds.ncross = 0; if constexpr (!CLIMB) lds.ready[C] = 1u; }
     const u32 leaf_start = n - 1;
 
     // leaves: collision.cl:55-63 (fillInternal) + collision.cl:128-141 (leafBounds)
