@@ -280,3 +280,16 @@ def test_another_build_of_the_library_can_be_selected():
     env["COLLISION_AMD_LIB"] = "/nonexistent/libcollision_hip.so"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(_lib._HERE.parent))
     assert out.returncode != 0
+
+
+def test_climb_names_the_in_chunk_nodes_of_the_karras_tree(oracle):
+    """csrc/lbvh.hip builds the nodes whose range lies inside one chunk of 256 sorted leaves bottom-up from the adjacent deltas
+    instead of by Karras' searches (collision.cl:81-121).  The CPU restatement of that climb must name exactly those nodes of the
+    oracle's tree, each with the oracle's other end and split -- distinct codes, heaps of equal codes, few distinct codes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("climb_prototype", Path(__file__).parent / "analysis" / "climb_prototype.py")
+    proto = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(proto)
+    rng = np.random.default_rng(17)
+    named = sum(proto.check(oracle, codes, rng) for codes in proto.scenes(rng, 18, 2500))
+    assert named > 10000

@@ -491,14 +491,16 @@ def test_dense_scenes_switch_to_chunked_allocation_on_their_own(hip_env, oracle)
 
 @pytest.mark.parametrize("order", [False, True])
 @pytest.mark.parametrize("scene", ["uniform_f32", "uniform_f64", "clustered", "ragged_last_packet", "tiny_capacity",
-                                   "back_to_back"])
+                                   "back_to_back", "back_to_back_450k", "back_to_back_clustered"])
 def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene, order):
     """From 1.5 M spheres on (and always with chunked allocation) the traversal's workgroups draw their packets from
     per-XCD counters instead of a fixed stride (csrc/bvh.hip: dynamic packet order; the counters are cleared by the tree
     build's last kernel).  col_debug_traverse bit 15 makes every size take that way: same arrays, same pair set, also
     when the same collider runs again (the counters must be cleared every time) and with a list that is too small.
     `order`: the walks are handed out by the cost the previous call's walks left in the collider's scratch (col_common.h: WALK
-    ORDER; garbage on a first call, real times on the later calls of "back_to_back") -- any order gives the same pairs."""
+    ORDER; garbage on a first call, real times on the later calls of "back_to_back") -- any order gives the same pairs.
+    Without `order` the back-to-back scenes take the sparse scenes' rule: the long walks of the previous call dealt over the
+    first round's batches, at raised priority (k_cross; a few rounds of packets per XCD at 450 k spheres)."""
     from collision_amd._lib import cdll
     lib = cdll()
     lib.col_debug_traverse(32768)
@@ -523,11 +525,15 @@ def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene, order
             assert len(pairs) == 1000 == len(pair_set(pairs)) and pair_set(pairs) <= pair_set(ref["pairs"])
         else:
             ctx, cq = hip_env
-            coords, radii = uniform_scene(200000, 0.004, "float32")
-            ref = oracle.collide(oracle.pad4(coords), radii, capacity=1 << 20)
+            if scene == "back_to_back_450k": coords, radii = uniform_scene(450000, 0.003, "float32")
+            elif scene == "back_to_back_clustered": coords, radii = clustered_scene(150000, 0.01, 0.002, "float32")
+            else: coords, radii = uniform_scene(200000, 0.004, "float32")
+            cap = 1 << 23 if scene == "back_to_back_clustered" else 1 << 20
+            ref = oracle.collide(oracle.pad4(coords), radii, capacity=cap)
+            assert ref["count"] <= cap
             collider = Collider(ctx, len(coords), 8, 256)
-            for _ in range(3):
-                count, pairs = run_collider(ctx, cq, collider, coords, radii, 1 << 20)
+            for _ in range(4 if scene != "back_to_back" else 3):
+                count, pairs = run_collider(ctx, cq, collider, coords, radii, cap)
                 assert count == ref["count"]
                 assert_same_pair_set(pairs, ref["pairs"])
     finally:
