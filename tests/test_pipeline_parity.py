@@ -526,7 +526,7 @@ def test_dynamic_packet_order_gives_the_same_pairs(hip_env, oracle, scene, order
         else:
             ctx, cq = hip_env
             if scene == "back_to_back_450k": coords, radii = uniform_scene(450000, 0.003, "float32")
-            elif scene == "back_to_back_clustered": coords, radii = clustered_scene(150000, 0.01, 0.002, "float32")
+            elif scene == "back_to_back_clustered": coords, radii = clustered_scene(60000, 0.01, 0.002, "float32")
             else: coords, radii = uniform_scene(200000, 0.004, "float32")
             cap = 1 << 23 if scene == "back_to_back_clustered" else 1 << 20
             ref = oracle.collide(oracle.pad4(coords), radii, capacity=cap)
