@@ -368,6 +368,141 @@ template <> struct ChunkDiag<true> { typedef ChunkDiagOn T; };
 __device__ __forceinline__ constexpr int chunk_mode(ChunkDiagOff) { return 0; }
 __device__ __forceinline__ int chunk_mode(ChunkDiagOn d) { return d.mode; }
 
+// WALK ORDER (col_common.h), workgroup `ob` of the 8 x COL_ORDER_SLICES that order the packets of the traversal that follows: part of
+// k_chunk's launch (the first workgroups of its grid: done long before the launch is) or, with the searching instances of k_chunk, of
+// k_cross's (where they were first, and made that launch 11 us instead of 5 at 1 M spheres).  n: this call's number of leaves.
+constexpr u32 COL_ORDER_SLICES = 8;     // workgroups per XCD that order its packets
+constexpr u32 COL_DEAL_UPTO = COL_DEAL_MAX_N / 512;      // packets per XCD up to which a sparse scene's long walks are dealt
+__device__ __forceinline__ void order_packets(u32 ob, u32 n, u32 n_bound, u32 *__restrict__ walk_order, int order_mode) {
+    // WALK ORDER (col_common.h): COL_ORDER_SLICES workgroups per XCD look at the costs the previous call's walks left for the
+    // XCD's packets and decide this call's order.  The statistics come from a sample of at most 1024 packets (every
+    // workgroup of the XCD takes the same one: 16 M spheres are 31 250 packets per XCD, and reading them all in one
+    // workgroup made this launch 105 us instead of 42).
+    __shared__ unsigned long long s_sum;
+    __shared__ u32 s_cnt[8], s_cur[8];
+    const u32 x = ob & 7u, g = ob >> 3, npk_bound = (n_bound + 63u) / 64u;
+    const u32 *cost = walk_order;
+    u32 *perm = walk_order + npk_bound;
+    u32 p_lo, p_end;
+    xcd_packet_range((n + 63u) / 64u, x, p_lo, p_end);
+    if (threadIdx.x == 0) s_sum = 0;
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 cnt = p_end > p_lo ? p_end - p_lo : 0u;
+    const u32 stride = (cnt + 1023u) / 1024u, nsamp = stride ? (cnt + stride - 1u) / stride : 0u;
+    u32 sample[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                  // (the four loads of a thread go out together: each is a round trip to memory)
+        const u32 e = threadIdx.x + 256u * k;
+        sample[k] = e < nsamp ? min(cost[p_lo + e * stride], 1u << 24) : 0u;        // (a first call's garbage, capped)
+    }
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine += sample[k];
+    atomicAdd(&s_sum, mine);
+    __syncthreads();
+    const unsigned long long mean = nsamp ? max(s_sum / nsamp, 1ull) : 1ull;
+    u32 *use_perm = walk_order + 2u * npk_bound + x;       // read by k_traverse's workgroups of this XCD
+    if (!cnt) { if (threadIdx.x == 0 && g == 0) *use_perm = 0; return; }
+    // Which order: decided by the caller (col_common.h, WALK ORDER).  The walks' times themselves do not tell a dense scene from a
+    // large sparse one -- a walk of a 16 M-sphere uniform scene takes 25 us among its 8191 neighbours, and a longest-first order
+    // there (it scatters a batch's 16 neighbouring packets, which walk nearly the same nodes, over the XCD's range) cost the
+    // traversal 15 %.
+    if (order_mode != 1) {
+        if (g) return;
+        // Moderate scenes (config 2: walks of 7..38 us around a mean of 13, the same packets long in every call): the kernel
+        // ends when the last long walk does, so the long walks (>= 1.5 x the mean: one packet in twelve) must START in the
+        // first round -- but SPREAD over it: a CU's scalar unit is what its 32 walks share, and long walks in a row (a
+        // longest-first list puts sixteen into one workgroup) only slow each other down.  So they are dealt over the leading
+        // slots of the XCD's first COL_TRAV_FIRST_BATCHES batches (one per workgroup of the traversal's grid), the longest
+        // class (>= 2 x) first; every other packet keeps its natural order in the slots that remain.
+        // ... and only where the launch is a few rounds long (up to COL_DEAL_UPTO packets on the XCD: 1.3 M spheres): the order costs
+        // every packet a dependent load of its number (1 M: - 1.6 us net of that; 2 M: + 6 us, `gpurun_out/order_ab_6.txt`)
+        const u32 nb1 = min(cnt / (u32)COL_TRAV_WAVES, (u32)COL_TRAV_FIRST_BATCHES);
+        if (nb1 == 0 || cnt > COL_DEAL_UPTO) {
+            if (threadIdx.x == 0) *use_perm = 0;          // natural order: k_traverse does not read perm[]
+            return;
+        }
+        const u32 thr2 = (u32)min(2ull * mean, 0xFFFFFFFFull), thr1 = (u32)min(mean + mean / 2, 0xFFFFFFFFull);
+        if (threadIdx.x < 2) s_cur[threadIdx.x] = 0;
+        constexpr int PER = (int)(COL_DEAL_UPTO + 255u) / 256;       // a thread's packets: PER consecutive ones from p_lo + PER * threadIdx.x
+        u32 mycost[PER];
+        const u32 q0 = p_lo + (u32)PER * threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < PER; k++) mycost[k] = q0 + k < p_end ? min(cost[q0 + k], 1u << 24) : 0u;
+        u32 my_shorts = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (q0 + k >= p_end) continue;
+            if (mycost[k] >= thr1) atomicAdd(&s_cnt[mycost[k] >= thr2 ? 0 : 1], 1u);
+            else my_shorts++;
+        }
+        __syncthreads();
+        const u32 l2 = s_cnt[0], l = l2 + s_cnt[1];
+        if (l == 0 || l > 8u * nb1) {
+            if (threadIdx.x == 0) *use_perm = 0;
+            return;
+        }
+        if (threadIdx.x == 0) *use_perm = 1;
+        const u32 per = l / nb1, rem = l % nb1;                      // batch j starts with per + (j < rem) long walks
+        const u32 cap_a = (u32)COL_TRAV_WAVES - per - 1u, cap_b = (u32)COL_TRAV_WAVES - per, in_a = rem * cap_a, in_ab = in_a + (nb1 - rem) * cap_b;
+        __shared__ u32 s_ws[4];
+        u32 tot;
+        u32 r = block_excl_scan<256>(my_shorts, s_ws, &tot);       // (one scan: the threads' runs of packets are in natural order)
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const u32 q = q0 + k, c = mycost[k];
+            if (q >= p_end) continue;
+            u32 pos;
+            if (c < thr1) {
+                if (r < in_a) pos = (r / cap_a) * (u32)COL_TRAV_WAVES + per + 1u + r % cap_a;
+                else if (r < in_ab) pos = (rem + (r - in_a) / cap_b) * (u32)COL_TRAV_WAVES + per + (r - in_a) % cap_b;
+                else pos = nb1 * (u32)COL_TRAV_WAVES + (r - in_ab);
+                r++;
+            } else {
+                const u32 kk = c >= thr2 ? atomicAdd(&s_cur[0], 1u) : l2 + atomicAdd(&s_cur[1], 1u);
+                pos = (kk % nb1) * (u32)COL_TRAV_WAVES + kk / nb1;
+            }
+            perm[p_lo + pos] = c < thr1 ? q : q | 0x80000000u;        // (bit 31: walked at raised priority)
+        }
+        return;
+    }
+    // Longest first: eight classes by cost * 4 / mean (capped), the longest class first, any order inside a class (an LDS
+    // cursor).  From 4096 packets the XCD's range is cut into COL_ORDER_SLICES slices, a workgroup each, and the slices' orders
+    // are interleaved (element k of slice g goes to place k * slices + g): longest first up to the slices' differences.
+    const u32 slices = cnt >= 4096u ? (u32)COL_ORDER_SLICES : 1u;
+    if (g >= slices) return;
+    if (threadIdx.x == 0 && g == 0) *use_perm = 1;
+    const u32 len = cnt / slices, longer = cnt % slices;                       // slice g: len + (g < longer) packets
+    const u32 s_lo = p_lo + g * len + min(g, longer), s_end = s_lo + len + (g < longer ? 1u : 0u);
+    // (four loads of a thread go out together in both passes: each is a round trip to memory)
+    auto cls_of = [&](u32 c) -> u32 { return (u32)min(7ull, (unsigned long long)c * 4ull / mean); };
+    for (u32 base = s_lo; base < s_end; base += 1024) {
+        u32 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const u32 q = base + 256u * k + threadIdx.x; c[k] = q < s_end ? min(cost[q], 1u << 24) : 0u; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (base + 256u * k + threadIdx.x < s_end) atomicAdd(&s_cnt[cls_of(c[k])], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 acc = 0; for (int k = 7; k >= 0; k--) { s_cur[k] = acc; acc += s_cnt[k]; } }
+    __syncthreads();
+    for (u32 base = s_lo; base < s_end; base += 1024) {
+        u32 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const u32 q = base + 256u * k + threadIdx.x; c[k] = q < s_end ? min(cost[q], 1u << 24) : 0u; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 q = base + 256u * k + threadIdx.x;
+            if (q >= s_end) continue;
+            const u32 cls = cls_of(c[k]);
+            const u32 kk = atomicAdd(&s_cur[cls], 1u);
+            perm[p_lo + (kk < len ? kk * slices + g : len * slices + g)] = cls >= 6u ? q | 0x80000000u : q;
+        }
+    }
+    return;
+}
+
 template <typename T, bool DIAG, typename I, bool DPP_SCAN = false, bool FAST_DELTA = false, bool CLIMB = false>
 __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, const u32 *__restrict__ ids,
                                              const T *__restrict__ coords, const T *__restrict__ radii,
@@ -375,7 +510,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial, u32 *__restrict__ cross,
                                              T *__restrict__ tab1, u32 n_bound, T block_k, const u32 *__restrict__ n_dev,
-                                             typename ChunkDiag<DIAG>::T diag) {
+                                             typename ChunkDiag<DIAG>::T diag, u32 *__restrict__ walk_order = nullptr, int order_mode = 0) {
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     const u32 n = count_of(n_bound, n_dev);  // (device-side count, col_common.h: the grid is sized for the bound)
     typedef typename BT<T>::V4 V4;
@@ -391,12 +526,19 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     // (with a device-side count the grid is sized for the bound: the first `nb` blocks -- dealt round-robin over the XCDs like
     // all blocks -- share the real chunks, the others leave; with the bound's chunk count in the formula two of eight XCDs sat idle
     // at a bound of 1.3 n: 70 instead of 51 us)
-    const u32 nb = n_dev ? (n + (u32)C - 1) / (u32)C : gridDim.x;
-    if (blockIdx.x >= nb) return;            // (n == 0 included)
-    u32 chunk = blockIdx.x;
+    // (CLIMB: with a walk order the first 8 x COL_ORDER_SLICES workgroups of the grid make it -- see order_packets)
+    const u32 nord = CLIMB && walk_order ? 8u * COL_ORDER_SLICES : 0u;
+    if (blockIdx.x < nord) {
+        order_packets(blockIdx.x, n, n_bound, walk_order, order_mode);
+        return;
+    }
+    const u32 bid = blockIdx.x - nord;
+    const u32 nb = n_dev ? (n + (u32)C - 1) / (u32)C : gridDim.x - nord;
+    if (bid >= nb) return;            // (n == 0 included)
+    u32 chunk = bid;
     if (!(dbg & 32)) {
-        const u32 q = nb / 8, r = nb % 8, x = blockIdx.x & 7u;
-        chunk = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+        const u32 q = nb / 8, r = nb % 8, x = bid & 7u;
+        chunk = x * q + (x < r ? x : r) + (bid >> 3);
     }
     const u32 c0 = chunk * C;
     const u32 p = c0 + tid;
@@ -769,8 +911,6 @@ struct Tabs { void *t[3]; };
 // `lin`: the table level whose sparse table was not built because it has at most LIN entries (one
 // launch less on inputs up to 2 M leaves); a range on that level is a short scan of its level-0 row.
 constexpr u32 LIN = 32;
-constexpr u32 COL_ORDER_SLICES = 8;     // workgroups per XCD that order its packets (k_cross)
-constexpr u32 COL_DEAL_UPTO = COL_DEAL_MAX_N / 512;      // packets per XCD up to which a sparse scene's long walks are dealt (k_cross)
 
 template <typename T>
 __device__ __forceinline__ void cross_node(T *__restrict__ bounds, const u32 *__restrict__ other_end, const T *__restrict__ partial,
@@ -813,118 +953,7 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
     const u32 n_bound = n;
     if (n_dev) { n = count_of(n, n_dev); nchunks = min(nchunks, (n + (u32)C - 1) / (u32)C); }
     if (blockIdx.x >= cross_blocks) {
-        // WALK ORDER (col_common.h): COL_ORDER_SLICES workgroups per XCD look at the costs the previous call's walks left for the
-        // XCD's packets and decide this call's order.  The statistics come from a sample of at most 1024 packets (every
-        // workgroup of the XCD takes the same one: 16 M spheres are 31 250 packets per XCD, and reading them all in one
-        // workgroup made this launch 105 us instead of 42).
-        __shared__ unsigned long long s_sum;
-        __shared__ u32 s_cnt[8], s_cur[8];
-        const u32 ob = blockIdx.x - cross_blocks, x = ob & 7u, g = ob >> 3, npk_bound = (n_bound + 63u) / 64u;
-        const u32 *cost = walk_order;
-        u32 *perm = walk_order + npk_bound;
-        u32 p_lo, p_end;
-        xcd_packet_range((n + 63u) / 64u, x, p_lo, p_end);
-        if (threadIdx.x == 0) s_sum = 0;
-        if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        const u32 cnt = p_end > p_lo ? p_end - p_lo : 0u;
-        const u32 stride = (cnt + 1023u) / 1024u, nsamp = stride ? (cnt + stride - 1u) / stride : 0u;
-        u32 sample[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {                  // (the four loads of a thread go out together: each is a round trip to memory)
-            const u32 e = threadIdx.x + 256u * k;
-            sample[k] = e < nsamp ? min(cost[p_lo + e * stride], 1u << 24) : 0u;        // (a first call's garbage, capped)
-        }
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) mine += sample[k];
-        atomicAdd(&s_sum, mine);
-        __syncthreads();
-        const unsigned long long mean = nsamp ? max(s_sum / nsamp, 1ull) : 1ull;
-        u32 *use_perm = walk_order + 2u * npk_bound + x;       // read by k_traverse's workgroups of this XCD
-        if (!cnt) { if (threadIdx.x == 0 && g == 0) *use_perm = 0; return; }
-        // Which order: decided by the caller (col_common.h, WALK ORDER).  The walks' times themselves do not tell a dense scene from a
-        // large sparse one -- a walk of a 16 M-sphere uniform scene takes 25 us among its 8191 neighbours, and a longest-first order
-        // there (it scatters a batch's 16 neighbouring packets, which walk nearly the same nodes, over the XCD's range) cost the
-        // traversal 15 %.
-        if (order_mode != 1) {
-            if (g) return;
-            // Moderate scenes (config 2: walks of 7..38 us around a mean of 13, the same packets long in every call): the kernel
-            // ends when the last long walk does, so the long walks (>= 1.5 x the mean: one packet in twelve) must START in the
-            // first round -- but SPREAD over it: a CU's scalar unit is what its 32 walks share, and long walks in a row (a
-            // longest-first list puts sixteen into one workgroup) only slow each other down.  So they are dealt over the leading
-            // slots of the XCD's first COL_TRAV_FIRST_BATCHES batches (one per workgroup of the traversal's grid), the longest
-            // class (>= 2 x) first; every other packet keeps its natural order in the slots that remain.
-            // ... and only where the launch is a few rounds long (up to COL_DEAL_UPTO packets on the XCD: 1.3 M spheres): the order costs
-            // every packet a dependent load of its number (1 M: - 1.6 us net of that; 2 M: + 6 us, `gpurun_out/order_ab_6.txt`)
-            const u32 nb1 = min(cnt / (u32)COL_TRAV_WAVES, (u32)COL_TRAV_FIRST_BATCHES);
-            if (nb1 == 0 || cnt > COL_DEAL_UPTO) {
-                if (threadIdx.x == 0) *use_perm = 0;          // natural order: k_traverse does not read perm[]
-                return;
-            }
-            const u32 thr2 = (u32)min(2ull * mean, 0xFFFFFFFFull), thr1 = (u32)min(mean + mean / 2, 0xFFFFFFFFull);
-            if (threadIdx.x < 2) s_cur[threadIdx.x] = 0;
-            constexpr int PER = (int)(COL_DEAL_UPTO + 255u) / 256;       // a thread's packets: q = p_lo + 256 * k + threadIdx.x
-            u32 mycost[PER];
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const u32 q = p_lo + 256u * k + threadIdx.x;
-                mycost[k] = q < p_end ? min(cost[q], 1u << 24) : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < PER; k++)
-                if (p_lo + 256u * k + threadIdx.x < p_end && mycost[k] >= thr1) atomicAdd(&s_cnt[mycost[k] >= thr2 ? 0 : 1], 1u);
-            __syncthreads();
-            const u32 l2 = s_cnt[0], l = l2 + s_cnt[1];
-            if (l == 0 || l > 8u * nb1) {
-                if (threadIdx.x == 0) *use_perm = 0;
-                return;
-            }
-            if (threadIdx.x == 0) *use_perm = 1;
-            const u32 per = l / nb1, rem = l % nb1;                      // batch j starts with per + (j < rem) long walks
-            const u32 cap_a = (u32)COL_TRAV_WAVES - per - 1u, cap_b = (u32)COL_TRAV_WAVES - per, in_a = rem * cap_a, in_ab = in_a + (nb1 - rem) * cap_b;
-            __shared__ u32 s_ws[4];
-            u32 shorts = 0;
-#pragma unroll
-            for (int kk = 0; kk < PER; kk++) {
-                const u32 q = p_lo + 256u * kk + threadIdx.x;
-                if (p_lo + 256u * kk >= p_end) break;
-                const u32 c = mycost[kk];
-                const bool is_short = q < p_end && c < thr1;
-                u32 tot;
-                const u32 r = shorts + block_excl_scan<256>(is_short ? 1u : 0u, s_ws, &tot);
-                shorts += tot;
-                if (q >= p_end) continue;
-                u32 pos;
-                if (is_short) {
-                    if (r < in_a) pos = (r / cap_a) * (u32)COL_TRAV_WAVES + per + 1u + r % cap_a;
-                    else if (r < in_ab) pos = (rem + (r - in_a) / cap_b) * (u32)COL_TRAV_WAVES + per + (r - in_a) % cap_b;
-                    else pos = nb1 * (u32)COL_TRAV_WAVES + (r - in_ab);
-                } else {
-                    const u32 k = c >= thr2 ? atomicAdd(&s_cur[0], 1u) : l2 + atomicAdd(&s_cur[1], 1u);
-                    pos = (k % nb1) * (u32)COL_TRAV_WAVES + k / nb1;
-                }
-                perm[p_lo + pos] = is_short ? q : q | 0x80000000u;        // (bit 31: walked at raised priority)
-            }
-            return;
-        }
-        // Longest first: eight classes by cost * 4 / mean (capped), the longest class first, any order inside a class (an LDS
-        // cursor).  From 4096 packets the XCD's range is cut into COL_ORDER_SLICES slices, a workgroup each, and the slices' orders
-        // are interleaved (element k of slice g goes to place k * slices + g): longest first up to the slices' differences.
-        const u32 slices = cnt >= 4096u ? (u32)COL_ORDER_SLICES : 1u;
-        if (g >= slices) return;
-        if (threadIdx.x == 0 && g == 0) *use_perm = 1;
-        const u32 len = cnt / slices, longer = cnt % slices;                       // slice g: len + (g < longer) packets
-        const u32 s_lo = p_lo + g * len + min(g, longer), s_end = s_lo + len + (g < longer ? 1u : 0u);
-        for (u32 q = s_lo + threadIdx.x; q < s_end; q += 256) atomicAdd(&s_cnt[min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean)], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) { u32 acc = 0; for (int k = 7; k >= 0; k--) { s_cur[k] = acc; acc += s_cnt[k]; } }
-        __syncthreads();
-        for (u32 q = s_lo + threadIdx.x; q < s_end; q += 256) {
-            const u32 cls = (u32)min(7ull, (unsigned long long)min(cost[q], 1u << 24) * 4ull / mean);
-            const u32 k = atomicAdd(&s_cur[cls], 1u);
-            perm[p_lo + (k < len ? k * slices + g : len * slices + g)] = cls >= 6u ? q | 0x80000000u : q;
-        }
+        order_packets(blockIdx.x - cross_blocks, n, n_bound, walk_order, order_mode);
         return;
     }
     const u32 t = blockIdx.x * 256 + threadIdx.x;
@@ -979,6 +1008,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     Tabs tabs;
     for (int h = 0; h < 3; h++) tabs.t[h] = scratch + L.tab[h];
     const u32 nchunks = L.count[0];
+    bool ordered_by_chunk = false;       // the production k_chunk orders the traversal's packets itself; otherwise k_cross does
     // mode bit 10 (1024) alone is not a diagnostics mode: it selects the round-3 production instance -- shuffle scans, branchy
     // delta() -- for A/Bs (tools/lbvh_scan_ab.py)
     // (bit 11 (2048), likewise: float64 keeps the shuffle scans -- the A/B of the float64 DPP scans)
@@ -990,8 +1020,11 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         k_chunk<T, false, int32_t, true, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                                  (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))       // production
-        k_chunk<T, false, int32_t, true, true, true><<<dim3(nchunks), dim3(C), (g_dbg & 16384) ? 24576 : 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
-                                                                                 (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
+    {
+        k_chunk<T, false, int32_t, true, true, true><<<dim3(nchunks + (walk_order ? 8u * COL_ORDER_SLICES : 0u)), dim3(C), (g_dbg & 16384) ? 24576 : 0, s>>>(
+            codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross, (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{}, walk_order, order_mode);
+        ordered_by_chunk = true;
+    }
     else if (n < (1u << 30) && !(g_dbg & 1024))
         k_chunk<T, false, int32_t, false, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                                   (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
@@ -1015,8 +1048,8 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         if (groups < 2) break;
     }
     const unsigned cross_blocks = (unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256);
-    k_cross<T><<<dim3(cross_blocks + (walk_order ? 8u * COL_ORDER_SLICES : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8, n_dev,
-                                                                                walk_order, cross_blocks, order_mode);
+    k_cross<T><<<dim3(cross_blocks + (walk_order && !ordered_by_chunk ? 8u * COL_ORDER_SLICES : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8,
+                                                                                                          n_dev, walk_order, cross_blocks, order_mode);
     COL_LAUNCH_OK();
     return COL_OK;
 }
