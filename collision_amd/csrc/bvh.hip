@@ -657,7 +657,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_num_sgpr(80))) void k_tra
         // stay inside one asm loop of 7 scalar instructions per step.  0.077 -> 0.069 ms, config 3 0.88 -> 0.80 ms.
         u32 idx = GHOST ? 0u : (u32)__builtin_amdgcn_readlane((int)qskip, last);      // ghosts: from the root
         if ((mode & 2) || only1) idx = END;
-        if (mode & (2048 | 4096)) {      // diagnostics (variant bits 24 / 25): the walk with the lower / upper half of the packet's queries only
+        if constexpr (PROF) if (mode & (2048 | 4096)) {      // profiling instance only (variant bits 24 / 25): the walk with the lower / upper half of the packet's queries
             const bool keep = (mode & 2048) ? lane < 32u : lane >= 32u;
             if (!keep) { lx = ly = lz = (T)INFINITY; hx = hy = hz = -(T)INFINITY; }
         }

@@ -21,9 +21,17 @@ extern "C" {
 
 int col_debug_xcc_census(void *stream, uint32_t *out, uint32_t nblocks);   /* diagnostics: XCC id per workgroup */
 int col_debug_walk_profile(uint32_t *out, uint32_t npackets);   /* diagnostics: see csrc/bvh.hip */
-void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid */
+void col_debug_traverse(int variant);   /* diagnostics: 0 packet walk (default), 1 lane-per-query, bit 1 vector record loads, bit 2 half grid;
+                                         * the other bits are listed where they act (csrc/bvh.hip launch_traverse): 12 profiling instance,
+                                         * 13 / 14 / 15 dynamic packet order forced / forbidden / at every size, 16 / 17 split units, 21 no walk
+                                         * order, 22 the first batch drawn from the counter too, 23 long walks at ordinary priority,
+                                         * 24 / 25 the walk with the lower / upper half of a packet's queries only (timing experiment:
+                                         * the pair set is then a subset) */
 void col_debug_lbvh(int mode);          /* diagnostics: timing ablations of k_chunk, 0 = off; 1024 alone = the production instance with the
-                                         * round-3 code (shuffle scans, branchy Karras probes) for A/Bs, not a diagnostics instance */
+                                         * round-3 code (shuffle scans, branchy Karras probes) for A/Bs, not a diagnostics instance; likewise
+                                         * 2048 (float64 with shuffle scans), 8192 (Karras' searches for every node instead of the climb),
+                                         * 16384 (24 KB of unused LDS per workgroup: half the resident workgroups); 4096: the traversal's
+                                         * longest-first walk order whatever the scene (tests) */
 void col_debug_leaf_blocks(float k);    /* leaf-block criterion of the fused LBVH build, process-wide: a node of <= 16 leaves is marked when it is at
                                          * most k leaf boxes wide on every axis; default 3, 0 = no marks, a huge k = every small node */
 void col_debug_radix(int mode);         /* diagnostics: 2 = coalesced output, 4 = blockIdx tile order, 8 = dword loads, 32 = phase stamps,
