@@ -213,20 +213,35 @@ template <typename T> __device__ __forceinline__ void links_store(T *bounds, uin
     p[7] = (Bits)down;
 }
 
-// LDS image of one chunk: leaf boxes, finished boxes of in-chunk internal nodes, ready flags.
-template <typename T> struct ChunkLds {
-    T leaf[6][C];
+// LDS image of one chunk: the leaves, finished boxes of in-chunk internal nodes, ready flags / meeting places.
+// Round 4, second half: the image is PACKED so that more workgroups than the CU's 32 wave slots admit fit its LDS (f32: 14.9 KB
+// = 12 granules of 1280 B: ten workgroups; it was 19.7 KB: eight) -- the waves of a workgroup that have no crossing node leave
+// right after their stores while the others search, and the wave slots they free are only of use to a NEW workgroup if the
+// LDS has room for it; float64 (25.3 KB, was 31.4) gets six workgroups per CU instead of five.
+//   leaf[4][C]  the leaf's sphere (x, y, z, r), not its box: the box is c -+ r wherever it is read -- the same two IEEE
+//               operations on the same operands as in the leaf's own thread, so the same bits -- and a third less LDS
+//   flags       the searching instances' ready[C + 1] ([C] = 1 for ever: the 'flag' of a child that is a leaf); CLIMB: meet[],
+//               two 16-bit places per word (a value is a far end + 1 <= 256; the first arrival ORs it into a zero place and
+//               sees zero, the second sees the first's value -- and spoils the place, which nobody reads again)
+//   adj         one signed byte per delta (-1 .. 63)
+//   oe, split   CLIMB: other end and split of node c0 + t as chunk-local positions in a byte each; oe[t] == t = not an
+//               in-chunk node (a node's range holds two leaves or more: its other end is never itself)
+template <typename T, bool CLIMB> struct ChunkLds {
+    T leaf[4][C];
     T node[6][C];
-    union {                             // (one or the other: 20 KB per workgroup are 8 workgroups per CU, 20.7 KB were 7)
-        u32 ready[C + 1];               // the searching instances; [C] = 1 for ever: the 'flag' of a child that is a leaf (no branch in the wait below)
-        u32 meet[C];                    // CLIMB: the two children of the node that splits behind position t meet here (far end + 1 of the first)
-    };
     T wave_tot[2][C / COL_WAVE][6];     // per-wave totals for the prefix / suffix scans
+    u32 flags[CLIMB ? C / 2 : C + 1];
     u32 ncross;                         // nodes of this chunk that cross its boundary, so far (see CROSS_CAP)
-    int adj[C + 1];                     // adj[1 + t] = delta(p, p + 1) of the chunk's position t, adj[0] = delta(c0 - 1, c0) (FAST_DELTA: see k_chunk)
-    u32 oe[C], split[C];                // CLIMB: other end and split of node c0 + t (chunk-local positions), NO_RANGE = not an in-chunk node
+    signed char adj[C + 4];             // adj[1 + t] = delta(p, p + 1) of the chunk's position t, adj[0] = delta(c0 - 1, c0) (FAST_DELTA: see k_chunk)
+    unsigned char oe[CLIMB ? C : 4], split[CLIMB ? C : 4];
 };
-constexpr u32 NO_RANGE = 0xFFFFFFFFu;
+template <typename T> __device__ __forceinline__ Box<T> leaf_get(const T (&a)[4][C], int pos) {
+    const T x = a[0][pos], y = a[1][pos], z = a[2][pos], r = a[3][pos];
+    Box<T> b;
+    b.lo[0] = x - r; b.lo[1] = y - r; b.lo[2] = z - r;
+    b.hi[0] = x + r; b.hi[1] = y + r; b.hi[2] = z + r;
+    return b;
+}
 // The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
 // a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
 // goes through all its nodes instead.
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     const u32 n = count_of(n_bound, n_dev);  // (device-side count, col_common.h: the grid is sized for the bound)
     typedef typename BT<T>::V4 V4;
-    __shared__ ChunkLds<T> lds;
+    __shared__ ChunkLds<T, CLIMB> lds;
     __shared__ u32 s_codes[WIN];
     const int tid = threadIdx.x, lane = tid & (COL_WAVE - 1), w = tid / COL_WAVE;
     // XCD-aware order: blockIdx % 8 is the XCD (each with its own L2).  Every XCD builds one contiguous run of chunks -- the
@@ -568,15 +583,15 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         const u32 cme = wcode[HALO / C];
         if (has_prev) d_prev = (int)min(ffbh_raw(cme ^ cprev), 32u + ffbh_raw(p ^ (p - 1u)));
         if (has_next) d_next = (int)min(ffbh_raw(cme ^ cnext), 32u + ffbh_raw(p ^ (p + 1u)));
-        lds.adj[1 + tid] = d_next;
-        if (tid == 0) lds.adj[0] = d_prev;
+        lds.adj[1 + tid] = (signed char)d_next;
+        if (tid == 0) lds.adj[0] = (signed char)d_prev;
     }
-    if constexpr (CLIMB) { lds.meet[tid] = 0; lds.oe[tid] = NO_RANGE; }
+    if constexpr (CLIMB) { if (tid < C / 2) lds.flags[tid] = 0; lds.oe[tid] = (unsigned char)tid; }
 #pragma unroll
     for (int k = 0; k < WIN / C; k++) s_codes[tid + k * C] = wcode[k];
-    if constexpr (!CLIMB) lds.ready[tid] = 0;
+    if constexpr (!CLIMB) lds.flags[tid] = 0;
     if (tid < (int)CROSS_CAP) cross[(uint64_t)chunk * CROSS_CAP + tid] = END;       // (complete before the barrier below: the fence of __syncthreads)
-    if (tid == 0) { lds.ncross = 0; if constexpr (!CLIMB) lds.ready[C] = 1u; }
+    if (tid == 0) { lds.ncross = 0; if constexpr (!CLIMB) lds.flags[C] = 1u; }
     const u32 leaf_start = n - 1;
 
     // leaves: collision.cl:55-63 (fillInternal) + collision.cl:128-141 (leafBounds)
@@ -599,8 +614,8 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         }
         leaf.lo[0] = c.x - r; leaf.lo[1] = c.y - r; leaf.lo[2] = c.z - r;
         leaf.hi[0] = c.x + r; leaf.hi[1] = c.y + r; leaf.hi[2] = c.z + r;
+        lds.leaf[0][tid] = c.x; lds.leaf[1][tid] = c.y; lds.leaf[2][tid] = c.z; lds.leaf[3][tid] = r;      // (a place beyond n is never read)
     }
-    soa_put(lds.leaf, tid, leaf);
 
     // inclusive prefix / suffix unions over the chunk (wave shuffles, then the 4 wave totals)
     Box<T> pre = leaf, suf = leaf;
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
     // union and goes on (Apetrei 2014, inside one chunk and in LDS).  One round costs what ONE of the search's probes did, a
     // thread climbs as far as it arrives second, and the boxes are merged on the way: no search (22 probes per wave), no waiting
     // for children.  A range whose sibling lies outside the chunk stops; its parent crosses the boundary and is found by the
-    // search below, like every node that the climb has not named (oe[] == NO_RANGE).
+    // search below, like every node that the climb has not named (oe[t] == t).
     if constexpr (CLIMB) {
         if (valid) {
             int l = tid, r = tid, my_split = 0;
@@ -662,21 +677,22 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                 if (!is_leaf) {
                     const int node = right ? r : l;
                     soa_put(lds.node, node, box);
-                    lds.oe[node] = (u32)(right ? l : r);
-                    lds.split[node] = (u32)my_split;
+                    lds.oe[node] = (unsigned char)(right ? l : r);
+                    lds.split[node] = (unsigned char)my_split;
                 }
                 const int g = right ? r : l - 1;
                 if ((dl & dr) < 0 || g < 0 || g >= C - 1) break;       // the root; or the sibling lies outside the chunk
                 // (LDS instructions of one wave are carried out in order: the box is in lds.node before the exchange, and the reads
                 // below come after it -- the compiler only has to keep that order)
                 asm volatile("" ::: "memory");
-                const u32 old = __hip_atomic_exchange(&lds.meet[g], (u32)(right ? l : r) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 place = 16u * ((u32)g & 1u);
+                const u32 old = (__hip_atomic_fetch_or(&lds.flags[g >> 1], ((u32)(right ? l : r) + 1u) << place, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> place) & 0xFFFFu;
                 asm volatile("" ::: "memory");
                 if (old == 0) break;                                    // first: the sibling will take it from here
                 const int far = (int)old - 1;
                 Box<T> sib;
-                if (right) { sib = far == g + 1 ? soa_get(lds.leaf, g + 1) : soa_get(lds.node, g + 1); r = far; }
-                else { sib = far == g ? soa_get(lds.leaf, g) : soa_get(lds.node, g); l = far; }
+                if (right) { sib = far == g + 1 ? leaf_get(lds.leaf, g + 1) : soa_get(lds.node, g + 1); r = far; }
+                else { sib = far == g ? leaf_get(lds.leaf, g) : soa_get(lds.node, g); l = far; }
                 box_merge(box, sib);
                 my_split = g;
                 is_leaf = false;
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         const u32 lo = min(i, j), hi = max(i, j);
         u32 down = child_a;
         if (hi - lo < COL_LEAF_BLOCK && n <= COL_LEAF_BLOCK_MAX_N && block_k > (T)0) {
-            const Box<T> first = soa_get(lds.leaf, (int)(lo - c0));
+            const Box<T> first = leaf_get(lds.leaf, (int)(lo - c0));
             bool dense = true;
 #pragma unroll
             for (int k = 0; k < 3; k++) dense = dense && (box.hi[k] - box.lo[k]) <= block_k * (first.hi[k] - first.lo[k]);
@@ -773,7 +789,7 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         // (Measured on the way: the searches compacted into the lanes of wave 0 behind two barriers: - 1 %; the same without
         // barriers, after wave 0's own output: + 15 %; 7 places per step in every lane of wave 0: + 9 % -- 300 instructions per step.)
         const bool inner = p < leaf_start;
-        const bool named = inner && lds.oe[tid] != NO_RANGE;
+        const bool named = inner && lds.oe[tid] != (unsigned char)tid;
         u32 skip, child_a;
         if (named) {
             const u32 j = c0 + lds.oe[tid];
@@ -866,14 +882,14 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         const int fa = a_leaf ? C : la, fb = b_leaf ? C : lb;      // both flags are read every round, unconditionally
         for (bool done = false; !done;) {
             // (relaxed loads + ONE acquire fence on success: two acquire loads are two serial LDS round trips per round)
-            const u32 ra = __hip_atomic_load(&lds.ready[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u32 rb = __hip_atomic_load(&lds.ready[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 ra = __hip_atomic_load(&lds.flags[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 rb = __hip_atomic_load(&lds.flags[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ra & rb) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                box = a_leaf ? soa_get(lds.leaf, la) : soa_get(lds.node, la);
-                box_merge(box, b_leaf ? soa_get(lds.leaf, lb) : soa_get(lds.node, lb));
+                box = a_leaf ? leaf_get(lds.leaf, la) : soa_get(lds.node, la);
+                box_merge(box, b_leaf ? leaf_get(lds.leaf, lb) : soa_get(lds.node, lb));
                 soa_put(lds.node, tid, box);
-                __hip_atomic_store(&lds.ready[tid], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&lds.flags[tid], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 done = true;
             }
         }

@@ -133,38 +133,74 @@ __global__ __launch_bounds__(RT) __attribute__((amdgpu_num_sgpr(80))) void k_his
     __syncthreads();
     const u32 b0 = blockIdx.x * g;
     const u32 cnt = min(g, nblocks - b0);
-    for (u32 t = 0; t < cnt; t++) {
-        const uint64_t base = (uint64_t)(b0 + t) * TILE;
-        if (base + TILE <= n) {
-            v4u q[NV];
+    // The next tile's keys are on their way while this tile is counted and folded (round 4: a workgroup used to issue a tile's
+    // loads only after the previous tile's fold -- one exposed round trip per tile with four workgroups on a CU).  The loads
+    // are asm statements so that hipcc leaves them where they are (it sinks plain loads below the LDS atomics), and every
+    // destination passes through an explicit wait before it is copied or used, with NO control flow between an asm load and
+    // its wait (cdna_hip_programming.md 5.7, form ii; k_scatter's lesson: hipcc does not know the registers are in flight and
+    // places its copies where it likes): the steady-state loop body is one basic block, the last full tile is peeled.
+    // Only the input's last tile can be ragged: it takes the guarded element-wise path.
+    const u32 m = cnt && (uint64_t)(b0 + cnt) * TILE > n ? cnt - 1 : cnt;        // this block's full tiles: [0, m)
+    auto issue = [&](v4u (&dst)[NV], uint64_t base) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) q[k] = *reinterpret_cast<const v4u *>(keys + base + ((uint64_t)k * RT + tid) * VEC);
+        for (int k = 0; k < NV; k++)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(keys + base + ((uint64_t)k * RT + tid) * VEC) : "memory");
+    };
+    auto arrived = [&](v4u (&dst)[NV]) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                K kk[VEC];
-                *reinterpret_cast<v4u *>(kk) = q[k];
+        for (int k = 0; k < NV; k++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst[k])::"memory");
+    };
+    auto fold = [&](u32 t) {         // between two barriers: digit `tid` folds its columns into row t and clears them
+        __syncthreads();
+        u32 sum = 0;
 #pragma unroll
-                for (int j = 0; j < VEC; j++) atomicAdd(&col[digit_of(kk[j], shift) * HC + c], 1u);
-            }
-        } else {
-            for (int k = 0; k < IT; k++) {
-                const uint64_t i = base + (uint64_t)k * RT + tid;
-                if (i < n) atomicAdd(&col[digit_of(keys[i], shift) * HC + c], 1u);
+        for (int j = 0; j < HC / 4; j++) {
+            v4u *p = reinterpret_cast<v4u *>(col + tid * HC + 4 * ((j + (tid >> 2)) & (HC / 4 - 1)));
+            const v4u v = *p;
+            sum += v.x + v.y + v.z + v.w;
+            *p = v4u{0, 0, 0, 0};
+        }
+        h[t * RDIG + tid] = sum;
+        __syncthreads();
+    };
+    auto count = [&](const v4u (&src)[NV]) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            K kk[VEC];
+            *reinterpret_cast<v4u *>(kk) = src[k];
+#pragma unroll
+            for (int j = 0; j < VEC; j++) atomicAdd(&col[digit_of(kk[j], shift) * HC + c], 1u);
+        }
+    };
+    if (m) {
+        v4u q[NV], qn[NV];
+        issue(q, (uint64_t)b0 * TILE);
+        arrived(q);
+        for (u32 t = 0; t + 1 < m; t++) {
+            if constexpr (NV <= 8) {
+                issue(qn, (uint64_t)(b0 + t + 1) * TILE);
+                count(q);
+                fold(t);
+                arrived(qn);
+#pragma unroll
+                for (int k = 0; k < NV; k++) q[k] = qn[k];
+            } else {                 // (the 16384-key tile: two tiles of keys are 128 registers -- one tile at a time, as before)
+                count(q);
+                fold(t);
+                issue(q, (uint64_t)(b0 + t + 1) * TILE);
+                arrived(q);
             }
         }
-        __syncthreads();
-        {   // digit `tid`: fold the columns, clear them
-            u32 sum = 0;
-#pragma unroll
-            for (int j = 0; j < HC / 4; j++) {
-                v4u *p = reinterpret_cast<v4u *>(col + tid * HC + 4 * ((j + (tid >> 2)) & (HC / 4 - 1)));
-                const v4u v = *p;
-                sum += v.x + v.y + v.z + v.w;
-                *p = v4u{0, 0, 0, 0};
-            }
-            h[t * RDIG + tid] = sum;
+        count(q);
+        fold(m - 1);
+    }
+    if (m < cnt) {
+        const uint64_t base = (uint64_t)(b0 + m) * TILE;
+        for (int k = 0; k < IT; k++) {
+            const uint64_t i = base + (uint64_t)k * RT + tid;
+            if (i < n) atomicAdd(&col[digit_of(keys[i], shift) * HC + c], 1u);
         }
-        __syncthreads();
+        fold(m);
     }
     // thread d writes its row of up to g entries (contiguous: full-sector writes)
     u32 *row = hist + (uint64_t)tid * nblocks + b0;
