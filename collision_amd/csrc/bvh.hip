@@ -1304,7 +1304,8 @@ __global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, 
 // (the list could then not be closed and is rebuilt the exact way: still min(count, capacity) valid pairs).
 template <typename T>
 int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const void *bounds,
-                            uint32_t n, void *scratch, const uint32_t *n_dev = nullptr, uint32_t *walk_order = nullptr) {
+                            uint32_t n, void *scratch, const uint32_t *n_dev = nullptr, uint32_t *walk_order = nullptr,
+                            bool hdr_cleared = false) {
     // (dynamic packet order, its counters in the header's pad: always -- a dense scene's packets differ by 5 x in time)
     const bool split = (n <= COL_SPLIT_UNITS_UPTO || (g_traverse_variant & 65536)) && !(g_traverse_variant & 131072);
     const int dyn = (g_traverse_variant & 16384) ? 0 : (split ? 256 | 512 : 256) | ((g_traverse_variant & 4194304) ? 128 : 0) | ((g_traverse_variant & 8388608) ? 1024 : 0);
@@ -1315,7 +1316,7 @@ int launch_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, ui
     hipStream_t s = col_stream(stream);
     const T *bd = (const T *)bounds;
     ChunkHdr *hdr = (ChunkHdr *)scratch;
-    COL_HIP(hipMemsetAsync(hdr, 0, 64, s));
+    if (!hdr_cleared) COL_HIP(hipMemsetAsync(hdr, 0, 64, s));        // (the whole path: the tree build's last kernel has cleared it)
     k_traverse<T, false, false, 1><<<g, t, 0, s>>>(pairs, counter, capacity, bd, n, (u64 *)hdr, 32 | dyn, NoGhost{}, n_dev,
                                                    (dyn & 256) && !(g_traverse_variant & 2097152) ? walk_order : nullptr);
     COL_LAUNCH_OK();
@@ -1430,14 +1431,14 @@ size_t col_traverse_chunked_scratch_bytes(void) { return sizeof(ChunkHdr); }
 // asm walks need); anything else takes col_traverse.  scratch: col_traverse_chunked_scratch_bytes().
 static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                                 const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev,
-                                uint32_t *walk_order = nullptr);
+                                uint32_t *walk_order = nullptr, bool hdr_cleared = false);
 int col_traverse_chunked(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                          const void *bounds, uint32_t n, int coord_bytes, void *scratch) {
     return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, scratch, nullptr);
 }
 static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter, uint32_t capacity, const col_node *nodes,
                                 const void *bounds, uint32_t n, int coord_bytes, void *scratch, const uint32_t *n_dev,
-                                uint32_t *walk_order) {
+                                uint32_t *walk_order, bool hdr_cleared) {
     const bool off32 = (coord_bytes == 4 || coord_bytes == 8) && (2ull * n - 1) * 8 * (unsigned)coord_bytes < (1ull << 32) &&
                        ((uintptr_t)bounds & 63) == 0;                                                // (see launch_traverse)
     if (!off32 || !scratch || (g_traverse_variant & ~(16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608)))
@@ -1450,8 +1451,8 @@ static int traverse_chunked_dev(void *stream, uint32_t *pairs, uint32_t *counter
     }
     if (n < 2) return COL_OK;
     if (capacity > 0 && !pairs) return COL_EINVAL;
-    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order);      // (round 4: the asm walk has a float64 form)
-    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order);
+    if (coord_bytes == 8) return launch_traverse_chunked<double>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order, hdr_cleared);      // (round 4: the asm walk has a float64 form)
+    return launch_traverse_chunked<float>(stream, pairs, counter, capacity, bounds, n, scratch, n_dev, walk_order, hdr_cleared);
 }
 
 // Diagnostics: same traversal, also accumulates stats[0..7] (8 x u64) = phase-2 steps, descents, leaf
@@ -1533,6 +1534,7 @@ int col_collide_plan_dev(void *stream, const void *coords, const void *radii, ui
     sort_plan &= 1;
     uint32_t *publish = oversize ? oversize + 2 : nullptr;      // the previous call's pair count, for the caller's next choice
     int rc;
+    uint32_t *report_word = nullptr;      // the LSD plan's bucket report rides in the tree build's first launch (lbvh.hip)
     const uint32_t tile = col_radix_tile(padded, 4, 4);
     if (tile == 1024 || tile == 4096 || tile == 8192) {
         // The front end is fused (every tile class of a (u32, u32) sort): the Morton kernel folds the bounds partials itself and
@@ -1550,7 +1552,7 @@ int col_collide_plan_dev(void *stream, const void *coords, const void *radii, ui
         else rc = col_radix_sort_ex(stream, codes0, codes1, ids0, ids1, padded, 4, 4, sort_scratch, 0, 1);
         if (rc) return rc;
         // the LSD plan was taken where the MSD plan could apply: tell the caller how clustered the codes are (oversize[1])
-        if (!msd && oversize && padded <= COL_MSD_MAX_N && (rc = col_radix_bucket_report(stream, codes1, padded, oversize + 1))) return rc;
+        if (!msd && oversize && padded <= COL_MSD_MAX_N) report_word = oversize + 1;
     } else {
         if (n_dev) return COL_EINVAL;            // (a forced tile class: diagnostics only)
         if ((rc = col_reduce(stream, coords, n, coord_bytes == 8 ? COL_F64 : COL_F32, 4, COL_OP_MINMAX, red_scratch, range))) return rc;
@@ -1566,8 +1568,10 @@ int col_collide_plan_dev(void *stream, const void *coords, const void *radii, ui
     // long walks over the first round; larger sparse scenes record and order nothing
     const int order_mode = chunked || col_lbvh_order_forced() ? 1 : 0;
     uint32_t *walk_order = n > 256 && (chunked || (sched && (n <= COL_DEAL_MAX_N || order_mode))) ? (uint32_t *)((char *)chunk_hdr + sizeof(ChunkHdr) + 256) : nullptr;
-    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes, sched, n_dev, walk_order, order_mode))) return rc;
-    if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev, walk_order);
+    // (chunked: the tree build's last kernel clears the walk's whole 64-byte header -- its memset was a launch of 4.8 us)
+    if ((rc = col_lbvh_ex(stream, codes1, ids1, coords, radii, packed, nodes, bounds, lbvh_scratch, n, coord_bytes,
+                          chunked ? (uint32_t *)chunk_hdr : sched, n_dev, walk_order, order_mode, chunked ? 16u : 8u, report_word, padded))) return rc;
+    if (chunked) return traverse_chunked_dev(stream, pairs, counter, capacity, nodes, bounds, n, coord_bytes, chunk_hdr, n_dev, walk_order, true);
     if (n < 2) return COL_OK;
     if (coord_bytes == 4) return launch_traverse<float>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev, walk_order);
     return launch_traverse<double>(stream, pairs, counter, capacity, bounds, n, nullptr, 0, sched, n_dev, walk_order);

@@ -26,10 +26,13 @@ extern "C" int col_morton_ex(void *stream, const void *coords, const void *radii
                              uint32_t *zero_word, uint32_t *publish);
 extern "C" int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                            const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes,
-                           uint32_t *zero8,       // zero8: eight words the last kernel clears (the traversal's packet counters), or NULL
+                           uint32_t *zero8,       // zero8: words the last kernel clears (the traversal's packet counters / chunk header), or NULL
                            const uint32_t *n_dev,    // device-side count (see col_morton_tile), or NULL
                            uint32_t *walk_order,     // the traversal's cost / order arrays (WALK ORDER below), or NULL
-                           int order_mode);          // 1: a dense scene -- longest walks first; 0: only deal the long walks of a small launch
+                           int order_mode,           // 1: a dense scene -- longest walks first; 0: only deal the long walks of a small launch
+                           uint32_t nzero = 8,       // how many words at zero8 (8: the packet counters; 16: the chunked walk's whole header)
+                           uint32_t *report_word = nullptr,   // col_radix_bucket_report's word: the report rides in k_chunk's launch (one
+                           uint32_t report_n = 0);            // extra workgroup), report_n = length of `codes` with its pads
 extern "C" int col_lbvh_order_forced(void);      // col_debug_lbvh bit 12: the tests' switch for order_mode 1 at every size
 extern "C" int col_radix_sort_msd_dev(void *stream, const uint32_t *keys, uint32_t *keys_out, const uint32_t *vals, uint32_t *vals_out,
                                       uint64_t n, void *scratch, uint32_t *oversize, const uint32_t *n_real_dev);   // radix.hip
@@ -77,6 +80,38 @@ static inline uint64_t col_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1)
 #ifdef __HIPCC__
 typedef unsigned long long u64;
 typedef unsigned int u32;
+// The largest top-digit bucket (code bits 22..29, the MSD plan's bucket digit) of `n` sorted 30-bit codes (pads 0xFFFFFFFF
+// behind them) -> *word, bit 31 set (col_radix_bucket_report, radix.hip).  One 256-thread block; s_start: 257 LDS words.
+// A device function because the whole path lets it ride in k_chunk's launch (lbvh.hip) instead of a launch of its own.
+__device__ __forceinline__ void col_bucket_report_block(const u32 *__restrict__ sorted, u32 n, u32 *word, u32 *s_start) {
+    const u32 d = threadIdx.x;
+    const u32 want = d << 22;
+    u32 lo = 0, hi = n;                        // first position whose code is >= want
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (sorted[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    s_start[d] = lo;
+    if (d == 0) {                              // end of bucket 255: the first pad (0xFFFFFFFF) or n
+        u32 l2 = 0, h2 = n;
+        while (l2 < h2) {
+            const u32 mid = l2 + ((h2 - l2) >> 1);
+            if (sorted[mid] < (1u << 30)) l2 = mid + 1; else h2 = mid;
+        }
+        s_start[256] = l2;
+    }
+    __syncthreads();
+    u32 cnt = s_start[d + 1] - s_start[d];
+#pragma unroll
+    for (int o = COL_WAVE / 2; o > 0; o >>= 1) cnt = max(cnt, (u32)__shfl_xor((int)cnt, o, COL_WAVE));
+    __syncthreads();
+    if ((d & 63u) == 0) s_start[d >> 6] = cnt;
+    __syncthreads();
+    if (d == 0) {
+        const u32 m = max(max(s_start[0], s_start[1]), max(s_start[2], s_start[3]));
+        __hip_atomic_store(word, 0x80000000u | min(m, 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 __device__ __forceinline__ u32 lane_id() { return __lane_id(); }
 

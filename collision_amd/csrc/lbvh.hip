@@ -525,7 +525,8 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
                                              col_node *__restrict__ nodes, T *__restrict__ bounds,
                                              u32 *__restrict__ other_end, T *__restrict__ partial, u32 *__restrict__ cross,
                                              T *__restrict__ tab1, u32 n_bound, T block_k, const u32 *__restrict__ n_dev,
-                                             typename ChunkDiag<DIAG>::T diag, u32 *__restrict__ walk_order = nullptr, int order_mode = 0) {
+                                             typename ChunkDiag<DIAG>::T diag, u32 *__restrict__ walk_order = nullptr, int order_mode = 0,
+                                             u32 *report_word = nullptr, u32 report_n = 0) {
     const int dbg = chunk_mode(diag);        // the constant 0 in the production instance
     const u32 n = count_of(n_bound, n_dev);  // (device-side count, col_common.h: the grid is sized for the bound)
     typedef typename BT<T>::V4 V4;
@@ -547,8 +548,15 @@ __global__ __launch_bounds__(C) void k_chunk(const u32 *__restrict__ gcodes, con
         order_packets(blockIdx.x, n, n_bound, walk_order, order_mode);
         return;
     }
+    // (CLIMB: the LSD plan's bucket report -- how clustered are the codes, for the caller's next choice of plan -- is the LAST
+    // workgroup of the grid: twenty dependent loads that used to be a launch of their own, 8.8 us on config 3)
+    const u32 nrep = CLIMB && report_word ? 1u : 0u;
+    if (nrep && blockIdx.x == gridDim.x - 1u) {
+        col_bucket_report_block(gcodes, report_n, report_word, s_codes);
+        return;
+    }
     const u32 bid = blockIdx.x - nord;
-    const u32 nb = n_dev ? (n + (u32)C - 1) / (u32)C : gridDim.x - nord;
+    const u32 nb = n_dev ? (n + (u32)C - 1) / (u32)C : gridDim.x - nord - nrep;
     if (bid >= nb) return;            // (n == 0 included)
     u32 chunk = bid;
     if (!(dbg & 32)) {
@@ -965,7 +973,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32 *__restrict__ other_end,
                                                const T *__restrict__ partial, const u32 *__restrict__ cross, Tabs tabs, u32 n,
                                                u32 nchunks, int lin, u32 *__restrict__ zero8, const u32 *__restrict__ n_dev,
-                                               u32 *__restrict__ walk_order, u32 cross_blocks, int order_mode) {
+                                               u32 *__restrict__ walk_order, u32 cross_blocks, int order_mode, u32 nzero) {
     const u32 n_bound = n;
     if (n_dev) { n = count_of(n, n_dev); nchunks = min(nchunks, (n + (u32)C - 1) / (u32)C); }
     if (blockIdx.x >= cross_blocks) {
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(256) void k_cross(T *__restrict__ bounds, const u32
         return;
     }
     const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (zero8 && t < 8) zero8[t] = 0;          // the packet counters of the traversal that follows (bvh.hip), no launch of their own
+    if (zero8 && t < nzero) zero8[t] = 0;      // the packet counters (or the whole chunk header) of the traversal that follows (bvh.hip), no launch of their own
     const u32 chunk = t / CROSS_CAP, slot = t % CROSS_CAP;
     if (chunk >= nchunks) return;
     if (cross[(uint64_t)chunk * CROSS_CAP + CROSS_CAP - 1] == CROSS_DENSE) {
@@ -1016,7 +1024,8 @@ Layout layout(uint32_t n, int coord_bytes) {
 
 template <typename T>
 int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const T *radii, const T *packed,
-        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev, u32 *walk_order, int order_mode) {
+        col_node *nodes, T *bounds, char *scratch, u32 n, u32 *zero8, const u32 *n_dev, u32 *walk_order, int order_mode,
+        u32 nzero, u32 *report_word, u32 report_n) {
     const Layout L = layout(n, sizeof(T));
     u32 *other_end = (u32 *)(scratch + L.other_end);
     T *partial = (T *)(scratch + L.partial);
@@ -1037,9 +1046,11 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
                                                                                  (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     else if (n < (1u << 30) && !(g_dbg & 1024) && !((g_dbg & 2048) && sizeof(T) == 8))       // production
     {
-        k_chunk<T, false, int32_t, true, true, true><<<dim3(nchunks + (walk_order ? 8u * COL_ORDER_SLICES : 0u)), dim3(C), (g_dbg & 16384) ? 24576 : 0, s>>>(
-            codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross, (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{}, walk_order, order_mode);
+        k_chunk<T, false, int32_t, true, true, true><<<dim3(nchunks + (walk_order ? 8u * COL_ORDER_SLICES : 0u) + (report_word ? 1u : 0u)), dim3(C), (g_dbg & 16384) ? 24576 : 0, s>>>(
+            codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross, (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{}, walk_order, order_mode,
+            report_word, report_n);
         ordered_by_chunk = true;
+        report_word = nullptr;          // done in that launch
     }
     else if (n < (1u << 30) && !(g_dbg & 1024))
         k_chunk<T, false, int32_t, false, true><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
@@ -1051,8 +1062,12 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
         k_chunk<T, false, int64_t><<<dim3(nchunks), dim3(C), 0, s>>>(codes, ids, coords, radii, packed, nodes, bounds, other_end, partial, cross,
                                                                      (T *)tabs.t[0], n, (T)g_block_k, n_dev, ChunkDiagOff{});
     COL_LAUNCH_OK();
+    if (report_word) {                  // (an instance of k_chunk without the report's workgroup: the report's own launch)
+        const int rc = col_radix_bucket_report((void *)s, codes, report_n, report_word);
+        if (rc) return rc;
+    }
     if (nchunks < 2) {                  // every node lives inside the single chunk: no k_cross, so clear the packet counters here
-        if (zero8) COL_HIP(hipMemsetAsync(zero8, 0, 8 * sizeof(u32), s));
+        if (zero8) COL_HIP(hipMemsetAsync(zero8, 0, nzero * sizeof(u32), s));
         return COL_OK;
     }
     int lin = -1;
@@ -1065,7 +1080,7 @@ int run(hipStream_t s, const u32 *codes, const u32 *ids, const T *coords, const 
     }
     const unsigned cross_blocks = (unsigned)col_ceil_div((uint64_t)nchunks * CROSS_CAP, 256);
     k_cross<T><<<dim3(cross_blocks + (walk_order && !ordered_by_chunk ? 8u * COL_ORDER_SLICES : 0u)), dim3(256), 0, s>>>(bounds, other_end, partial, cross, tabs, n, nchunks, lin, zero8,
-                                                                                                          n_dev, walk_order, cross_blocks, order_mode);
+                                                                                                          n_dev, walk_order, cross_blocks, order_mode, nzero);
     COL_LAUNCH_OK();
     return COL_OK;
 }
@@ -1083,16 +1098,16 @@ size_t col_lbvh_scratch_bytes(uint32_t n, int coord_bytes) { return layout(n, co
 // `packed`: optional (x, y, z, r) rows indexed like coords (see col_morton_ex); coords/radii are then unused.
 int col_lbvh_ex(void *stream, const uint32_t *codes, const uint32_t *ids, const void *coords, const void *radii,
                 const void *packed, col_node *nodes, void *bounds, void *scratch, uint32_t n, int coord_bytes, uint32_t *zero8,
-                const uint32_t *n_dev, uint32_t *walk_order, int order_mode) {
+                const uint32_t *n_dev, uint32_t *walk_order, int order_mode, uint32_t nzero, uint32_t *report_word, uint32_t report_n) {
     if (n == 0) return COL_OK;
-    if (n >= 0x80000000u) return COL_EINVAL;
+    if (n >= 0x80000000u || nzero > 256u) return COL_EINVAL;
     if (!scratch) return COL_ENOSCRATCH;
     if (coord_bytes == 4)
         return run<float>(col_stream(stream), codes, ids, (const float *)coords, (const float *)radii, (const float *)packed,
-                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode);
+                          nodes, (float *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode, nzero, report_word, report_n);
     if (coord_bytes == 8)
         return run<double>(col_stream(stream), codes, ids, (const double *)coords, (const double *)radii,
-                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode);
+                           (const double *)packed, nodes, (double *)bounds, (char *)scratch, n, zero8, n_dev, walk_order, order_mode, nzero, report_word, report_n);
     return COL_EINVAL;
 }
 

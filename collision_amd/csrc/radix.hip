@@ -261,6 +261,9 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 
     unsigned long long t_prev = (DIAG && (dbg & 32)) ? __builtin_amdgcn_s_memtime() : 0ull;
     (void)t_prev;
+    // (diagnostics, wave priorities by phase -- modes 1 << 23: the store phase raised; 1 << 27: the load phase raised;
+    // 1 << 28: the ranking raised; 1 << 29: an s_sleep between the store phase's steps.  EXPERIMENTS.md R4.14)
+    if (DIAG && (dbg & (1 << 27))) __builtin_amdgcn_s_setprio(3);
     // this tile's global offset of digit `tid`: one scattered 4-byte load per thread, issued now so that
     // its latency hides under the loads and the ranking instead of sitting between two barriers
     const u32 my_offset = tid < RDIG ? offsets[(uint64_t)tid * nblocks + b] : 0u;
@@ -351,8 +354,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
             }
         }
     }
+    if (DIAG && (dbg & (1 << 27))) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     STAMP(0)      // load + transpose
+    if (DIAG && (dbg & (1 << 28))) __builtin_amdgcn_s_setprio(3);
 
     // (diagnostics, mode 65536: the input IS the pass's tile-sorted image (mode 2 wrote it) -- an element's slot is its
     // own index, the digit counts come from the offsets table: no match-any, no counters.  Everything else -- loads,
@@ -393,6 +398,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
 #pragma unroll
         for (int k = 0; k < IT; k++) val[k] = vstage[k * COL_WAVE + lane];
     }
+    if (DIAG && (dbg & (1 << 28))) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     STAMP(1)      // ranking
 
@@ -456,9 +462,11 @@ __global__ __launch_bounds__(NT) void k_scatter(const K *__restrict__ keys_in, K
     // storing them as one 4-byte-aligned dwordx4 -- 8 store instructions per thread instead of 32 -- is
     // 9 % faster with the output forced coalesced and 2-10 % SLOWER on the real runs, even when every
     // store hits L2: misaligned 16-byte stores are split in the address unit.)
+    if (DIAG && (dbg & (1 << 23))) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int k = 0; k < IT; k++) {
         const u32 i = k * NT + tid;
+        if (DIAG && (dbg & (1 << 29)) && k) __builtin_amdgcn_s_sleep(2);
         if (i < valid) {
             const K kk = s_keys[i];
             u32 g = s_goff[digit_of(kk, shift)] + i;
@@ -1151,34 +1159,9 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
 // word.  A bucket above the MSD finish's capacity means the MSD plan WOULD take its slow path: the caller
 // (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a second probe.  One small launch.
 __global__ __launch_bounds__(RDIG) void k_bucket_report(const u32 *__restrict__ sorted, u32 n, u32 *word) {
+    static_assert(BS_SHIFT_REPORT == 22 && RDIG == 256, "col_bucket_report_block (col_common.h) is written for this digit");
     __shared__ u32 s_start[RDIG + 1];
-    const u32 d = threadIdx.x;
-    const u32 want = d << BS_SHIFT_REPORT;
-    u32 lo = 0, hi = n;                        // first position whose code is >= want
-    while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        if (sorted[mid] < want) lo = mid + 1; else hi = mid;
-    }
-    s_start[d] = lo;
-    if (d == 0) {                              // end of bucket 255: the first pad (0xFFFFFFFF) or n
-        u32 l2 = 0, h2 = n;
-        while (l2 < h2) {
-            const u32 mid = l2 + ((h2 - l2) >> 1);
-            if (sorted[mid] < (1u << 30)) l2 = mid + 1; else h2 = mid;
-        }
-        s_start[RDIG] = l2;
-    }
-    __syncthreads();
-    u32 cnt = s_start[d + 1] - s_start[d];
-#pragma unroll
-    for (int o = COL_WAVE / 2; o > 0; o >>= 1) cnt = max(cnt, (u32)__shfl_xor((int)cnt, o, COL_WAVE));
-    __syncthreads();
-    if ((d & 63u) == 0) s_start[d >> 6] = cnt;
-    __syncthreads();
-    if (d == 0) {
-        const u32 m = max(max(s_start[0], s_start[1]), max(s_start[2], s_start[3]));
-        __hip_atomic_store(word, 0x80000000u | min(m, 0x7FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    col_bucket_report_block(sorted, n, word, s_start);
 }
 
 // MSD sort of (u32 key, u32 value) pairs whose keys are 30-bit codes (or 0xFFFFFFFF pads), for inputs up to

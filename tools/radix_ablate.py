@@ -24,7 +24,9 @@ ms = bench.time_events(hip, cq, copy, 5)
 print("hipMemcpy d2d keys+vals: %.4f ms  %.0f GB/s" % (ms, n * 16 / ms / 1e6))
 modes = ((0, "production"), (1 << 30, "production (diag instance)"), (2, "coalesced write"), (4, "blockIdx tile order"),
          (64, "non-temporal loads"), (32768, "4 MiB output window (stores hit L2)"),
-         (8192, "every run an aligned 128-byte cell of its own"), (16384, "(key, value) pairs interleaved in one output"), (1024, "one resident block per CU (+18 KB LDS)"))
+         (8192, "every run an aligned 128-byte cell of its own"), (16384, "(key, value) pairs interleaved in one output"), (1024, "one resident block per CU (+18 KB LDS)"),
+         (1 << 23, "store phase at raised wave priority"), (1 << 27, "load phase at raised wave priority"),
+         (1 << 28, "ranking at raised wave priority"), (1 << 29, "s_sleep between the store steps"))
 if len(sys.argv) > 2:
     want = set(int(x) for x in sys.argv[2].split(","))
     modes = tuple(m for m in modes if m[0] in want)
