@@ -244,8 +244,10 @@ template <typename T> __device__ __forceinline__ Box<T> leaf_get(const T (&a)[4]
 }
 // The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
 // a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
-// goes through all its nodes instead.
-constexpr u32 CROSS_CAP = 16, CROSS_DENSE = 0xFFFFFFFEu;
+// goes through all its nodes instead.  (32 since the end of round 4: a chunk of a uniform scene has ~8 crossing nodes, one of a
+// clustered scene -- deeper trees -- often more than 15, and a dense chunk costs k_cross sixteen dependent rounds: config 3's
+// k_cross 15 -> 6 us, whole step 0.515 -> 0.505 ms; 64 gains nothing more and costs the 16 M launch 1 %.)
+constexpr u32 CROSS_CAP = 32, CROSS_DENSE = 0xFFFFFFFEu;
 template <typename T> __device__ __forceinline__ Box<T> soa_get(const T (&a)[6][C], int pos) {
     Box<T> b;
 #pragma unroll
