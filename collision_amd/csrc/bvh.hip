@@ -1282,20 +1282,35 @@ __global__ __launch_bounds__(256) void k_pairs_compact(u32 *__restrict__ pairs, 
     }
     __syncthreads();
     const u32 moves = s_low[512];
-    for (u32 k = blockIdx.x * 256 + tid; k < moves; k += gridDim.x * 256) {
-        // destination: the k-th hole slot below T
-        u32 lo = 0, hi = 511;                      // last i with s_low[i] <= k
-        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_low[mid] <= k) lo = mid; else hi = mid - 1; }
-        const u32 dst = s_start[lo] + (k - s_low[lo]);
-        // source: the k-th pair at / beyond T: behind the last hole i with s_fill[i] <= k, or before the first one
-        u32 src;
-        if (k < s_fill[0]) src = T + k;
-        else {
-            lo = 0; hi = 511;
-            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_fill[mid] <= k) lo = mid; else hi = mid - 1; }
-            src = s_e[lo] + (k - s_fill[lo]);
+    // Four moves per thread and round, their searches side by side: both are nine steps over 512 sorted entries, written without
+    // branches (step 256, 128, .. 1: the candidate index never passes 511), so that the 4 x 18 dependent LDS reads of a round overlap
+    // and its four pairs are on their way together (one move at a time: 18.5 us for config 3's 2 M moves; R4.20).
+    constexpr int MV = 4;
+    const u32 stride = gridDim.x * 256;
+    for (u32 k0 = blockIdx.x * 256 + tid; k0 < moves; k0 += MV * stride) {
+        u32 kk[MV], lo1[MV], lo2[MV];
+#pragma unroll
+        for (int u = 0; u < MV; u++) { kk[u] = min(k0 + u * stride, moves - 1u); lo1[u] = 0; lo2[u] = 0; }
+#pragma unroll
+        for (u32 step = 256; step; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < MV; u++) {
+                if (s_low[lo1[u] + step] <= kk[u]) lo1[u] += step;       // -> the last i with s_low[i] <= k (s_low[0] = 0)
+                if (s_fill[lo2[u] + step] <= kk[u]) lo2[u] += step;      // -> the last i with s_fill[i] <= k, if s_fill[0] <= k
+            }
         }
-        *reinterpret_cast<uint2 *>(pairs + 2ull * dst) = *reinterpret_cast<const uint2 *>(pairs + 2ull * src);
+        uint2 pr[MV];
+        u32 dst[MV];
+#pragma unroll
+        for (int u = 0; u < MV; u++) {
+            // destination: the k-th hole slot below T; source: the k-th pair at / beyond T -- behind hole lo2, or before the first hole
+            dst[u] = s_start[lo1[u]] + (kk[u] - s_low[lo1[u]]);
+            const u32 src = kk[u] < s_fill[0] ? T + kk[u] : s_e[lo2[u]] + (kk[u] - s_fill[lo2[u]]);
+            pr[u] = *reinterpret_cast<const uint2 *>(pairs + 2ull * src);
+        }
+#pragma unroll
+        for (int u = 0; u < MV; u++)
+            if (k0 + u * stride < moves) *reinterpret_cast<uint2 *>(pairs + 2ull * dst[u]) = pr[u];
     }
 }
 
