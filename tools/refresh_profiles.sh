@@ -12,6 +12,19 @@ S=gpurun_out/summary
   echo "# k_dbg_copy / k_dbg_tile_copy are the copy-ceiling leg (roofline.copy_ceiling).  bench.py's roofline = MEDIAN of 200 steady-state"
   echo "# pass-0 launches (one HIP event per launch): compare with median_us.  k_traverse / k_chunk rows: the 1 M path (config 2) plus"
   echo "# the config-3 (clustered, 25 M pairs: chunked allocation + k_pairs_compact), 2 M and 16 M steps and the reference's benchmark shapes."
+  # the bench line this very run printed (same box, under the profiler), next to the one filed as ${R}_bench_final.json (another lease)
+  python - <<PY
+import json
+try:
+    mine = [json.loads(l) for l in open("gpurun_out/prof_bench.log") if l.startswith("{") and '"metric"' in l][-1]
+    filed = json.loads(open("gpurun_out/bench_final.json").read().strip().splitlines()[-1])
+    print("# THIS run's own bench line (the profiled process, this box): roofline launch_ms %.4f (frac %.4f), ms_per_step %.4f;  the line filed as"
+          % (mine["roofline"]["launch_ms"], mine["roofline"]["frac"], mine["ms_per_step"]))
+    print("# ${R}_bench_final.json comes from another lease (boxes differ by +- 6 %% on this kernel): launch_ms %.4f (frac %.4f), ms_per_step %.4f."
+          % (filed["roofline"]["launch_ms"], filed["roofline"]["frac"], filed["ms_per_step"]))
+except Exception as exc:
+    print("# (no bench line of the profiled run: %r)" % (exc,))
+PY
   cat $S/bench_kernel_stats.txt; } > profiles/${R}_bench_kernel_stats.txt
 cp $S/radix64M_pmc.json profiles/${R}_radix64M_pmc.json
 cp $S/path1M_pmc.json profiles/${R}_path1M_pmc.json
