@@ -64,7 +64,7 @@ class Collider:
         # is 6 launches shorter but wants every top-digit bucket to fit one workgroup's LDS.  A kernel that
         # meets a larger bucket sorts it anyway (slowly) and says so in a pinned host word; the next calls
         # then take the LSD sort, and every LSD call reports the largest MSD bucket of its codes (read off the
-        # sorted codes: one small launch): while that says a bucket could not fit, the MSD
+        # sorted codes by the last workgroup of the tree build's first launch): while that says a bucket could not fit, the MSD
         # plan is not tried at all -- a clustered scene pays for ONE slow probe, not one every PLAN_RETRY
         # calls; when it no longer says so, the MSD plan is tried again after PLAN_RETRY calls (doubling up to
         # PLAN_RETRY_MAX while it keeps failing).  No host sync: the words are read when the next call is made

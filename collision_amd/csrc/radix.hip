@@ -1157,7 +1157,8 @@ int col_radix_scatter(void *stream, const void *keys, void *keys_out, const void
 // After an LSD sort of 30-bit codes: the size of the largest MSD bucket (codes sharing bits 22..29) read off the SORTED
 // codes -- thread d finds where bucket d starts by a binary search -- published as 0x80000000 | max in a host-visible
 // word.  A bucket above the MSD finish's capacity means the MSD plan WOULD take its slow path: the caller
-// (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a second probe.  One small launch.
+// (collision_amd/collision.py) then does not try it -- clustered scenes never pay for a second probe.  One small launch as col_radix_bucket_report;
+// inside col_collide the same code (col_bucket_report_block, col_common.h) is the last workgroup of k_chunk's grid (lbvh.hip).
 __global__ __launch_bounds__(RDIG) void k_bucket_report(const u32 *__restrict__ sorted, u32 n, u32 *word) {
     static_assert(BS_SHIFT_REPORT == 22 && RDIG == 256, "col_bucket_report_block (col_common.h) is written for this digit");
     __shared__ u32 s_start[RDIG + 1];
