@@ -244,9 +244,10 @@ template <typename T> __device__ __forceinline__ Box<T> leaf_get(const T (&a)[4]
 }
 // The 1-2 % of nodes that cross a chunk boundary are listed per chunk for k_cross: CROSS_CAP words per chunk, END = free;
 // a chunk with more than CROSS_CAP - 1 of them (deep trees: duplicate codes) sets the last word to CROSS_DENSE and k_cross
-// goes through all its nodes instead.  (32 since the end of round 4: a chunk of a uniform scene has ~8 crossing nodes, one of a
-// clustered scene -- deeper trees -- often more than 15, and a dense chunk costs k_cross sixteen dependent rounds: config 3's
-// k_cross 15 -> 6 us, whole step 0.515 -> 0.505 ms; 64 gains nothing more and costs the 16 M launch 1 %.)
+// goes through all its nodes instead.  (32 since the end of round 4.  tests/analysis/crossing_nodes_per_chunk.py: a chunk has 8.3
+// crossing nodes on average, at most 14 on config 2 -- and up to 21 on config 3, where 13 of the 3907 chunks had more than 15: a
+// handful of dense chunks, sixteen dependent rounds each, were enough to hold k_cross for 15 us instead of 5.7; whole step 0.515 ->
+// 0.505 ms; 64 gains nothing more and costs the 16 M launch 1 %.)
 constexpr u32 CROSS_CAP = 32, CROSS_DENSE = 0xFFFFFFFEu;
 template <typename T> __device__ __forceinline__ Box<T> soa_get(const T (&a)[6][C], int pos) {
     Box<T> b;
